@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the full VAE training step (fwd + BCE/KL loss + bwd + gradient
+all-reduce + Adam) on N MI355X GPUs, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config 3): 128x128x3 images, latent 128, 32 images per GPU
+(global batch 256 at 8 GPUs -> weak scaling), synthetic uniform[0,1) pixels, random-init weights
+(VaeGan.init_parameters rule, seed 0), fp32 arithmetic on the f32 MFMA path, Adam(lr=1e-4).
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel family of the step (the
+5x5 implicit-GEMM convolutions, MFMA-bound): algorithmic FLOPs of its launches / their summed
+HIP-event durations inside the timed region.  `cpu_baseline` times the CPU oracle
+(oracle/ref_cpu.py = the reference's torch-CPU algorithm) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic GFLOP per image for one training step (fwd + dgrad + wgrad, transposed
+# convs without zero insertion)
+STEP_GFLOP = {32: 0.6141, 64: 4.0301, 128: 22.2088, 256: 112.0225}
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--img", type=int, default=128)
+    ap.add_argument("--z", type=int, default=128)
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph "
+                    "(roofline events are then taken in a separate instrumented pass)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (= reference algorithm on torch CPU) on the host cores: bounded sample."""
+    from oracle import ref_cpu as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, C, S, z = args.batch_per_gpu, args.channels, args.img, args.z
+    L = O.iter_level_for(S)
+    p = O.init_params(C, z, L, seed=0)
+    O.require_grad(p)
+    opt = O.make_optimizer(p, "adam", 1e-4)
+    x, eps = O.synthetic_batch(B, C, S, z)
+    O.train_step(p, opt, x, eps, L)  # warm-up
+    best = float("inf")
+    for _ in range(args.cpu_steps):
+        t0 = time.perf_counter()
+        O.train_step(p, opt, x, eps, L)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(B / best, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_steps} timed steps (best) after 1 warm-up, batch {B}, {S}x{S}x{C}, z={z}, "
+                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import vae_play_amd as V
+    from vae_play_amd import engine, optim, parallel
+
+    B, C, S, z = args.batch_per_gpu, args.channels, args.img, args.z
+    torch.manual_seed(0)
+    vae = V.VAE(S, z, C, init_rule=True).to("cuda").train()     # same seed on every rank = replicated weights
+    opt = optim.Adam(vae.parameters(), lr=1e-4)
+    parallel.broadcast_flat_params(opt.flat_param, 0)
+    fused = engine.FusedVAEStep(vae, opt, B, S, C)
+    gx = torch.Generator().manual_seed(1234 + rank)
+    ge = torch.Generator().manual_seed(4321 + rank)
+    x = torch.rand(B, C, S, S, generator=gx).cuda()               # inputs resident in HBM before timing
+    eps = torch.randn(B, z, generator=ge).cuda()
+    if args.graph:
+        fused.capture()
+
+    for _ in range(args.warmup):
+        fused.step(x, eps)
+
+    timers = None if args.graph else {"names": CONV_CALLS, "events": []}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, recon, kl = fused.step(x, eps, timers)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    final_loss = loss.item()
+
+    measured = "timed-region"
+    if timers is None:  # graph replay cannot carry events: instrumented eager pass of the same K steps
+        timers = {"names": CONV_CALLS, "events": []}
+        for _ in range(args.steps):
+            fused.forward_backward(x, eps, timers)
+        torch.cuda.synchronize()
+        measured = "instrumented-pass-after-timed-region"
+
+    if rank == 0:
+        fam = {}
+        for name, tag, flops, e0, e1 in timers["events"]:
+            d = fam.setdefault(name, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += 1
+        dom = max(fam, key=lambda k: fam[k][1])
+        tot_f = sum(v[0] for v in fam.values())
+        tot_t = sum(v[1] for v in fam.values())
+        ach = fam[dom][0] / fam[dom][1] / 1e12
+        ips = world * B * args.steps / elapsed
+        out = {
+            "metric": "images/sec (train step, 128x128 VAE)", "value": round(ips, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"networks VAE {S}x{S}x{C} latent={z} train step (fwd+BCE/KL+bwd+allreduce+Adam), "
+                                   f"{B} images/GPU, global batch {B * world}", "parallelism": f"dp{world}",
+                       "per_gpu_batch": B, "global_batch": B * world, "graph": bool(args.graph)},
+            "images_per_sec_per_gpu": round(ips / world, 1),
+            "step_mfma_frac": round(ips / world * STEP_GFLOP.get(S, 0.0) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "loss": round(final_loss, 4),
+            "roofline": {"bound": "mfma", "kernel": dom + " (igemm_kernel, v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches": fam[dom][2], "avg_launch_ms": round(fam[dom][1] / fam[dom][2] * 1e3, 4),
+                         "all_conv_families_tflops": round(tot_f / tot_t / 1e12, 2),
+                         "conv_share_of_step_time": round(tot_t / args.steps / (elapsed / args.steps), 3),
+                         "measured": measured},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/* vaeplay_hip.h -- C ABI of libvaeplay_hip.so, the MI355X (gfx950) back end of the
+ * convolutional-VAE training step of kungyao/vae-play.
+ *
+ * The reference has no FFI of its own (pure PyTorch): the boundary it exposes is
+ * nn.Module.forward / loss / optimizer.step.  Every entry point below replaces the ATen/cuDNN
+ * call that a reference line dispatches; the citation after each prototype names that line
+ * (paths relative to the reference checkout).  The host binds them with ctypes
+ * (vae_play_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers owned by the caller
+ *     (PyTorch's allocator); the library never allocates or frees device memory and keeps no
+ *     pointer after return;
+ *   - activations are NHWC fp32 (= torch channels_last), weights are passed in the reference's
+ *     own layouts unless a prototype says "packed";
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no internal sync;
+ *   - return 0 on success, a negative vp_status otherwise; vp_last_error() gives the message
+ *     for the calling thread; nothing throws across the ABI;
+ *   - `ws`/`ws_bytes`: caller-provided scratch, size from the matching *_workspace_bytes().
+ */
+#ifndef VAEPLAY_HIP_H
+#define VAEPLAY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vp_stream; /* hipStream_t */
+
+enum vp_status { VP_OK = 0, VP_ERR_ARG = -1, VP_ERR_LAUNCH = -2, VP_ERR_WORKSPACE = -3, VP_ERR_STATE = -4 };
+enum vp_act { VP_ACT_NONE = 0, VP_ACT_RELU = 1, VP_ACT_LRELU = 2, VP_ACT_TANH = 3, VP_ACT_SIGMOID = 4 };
+
+int vp_abi_version(void);
+const char* vp_last_error(void);
+
+/* ---- layout ------------------------------------------------------------------------------ */
+/* NCHW <-> NHWC copies (module I/O is NCHW like the reference's tensors, datasets/dataset.py:68) */
+int vp_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, vp_stream stream);
+int vp_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, vp_stream stream);
+
+/* 5x5 weight repack.  w_ref is the reference tensor W[Csmall][Cbig][5][5]
+ * (nn.Conv2d weight (Cout,Cin,5,5) models/networks.py:14; nn.ConvTranspose2d weight
+ * (Cin,Cout,5,5) models/networks.py:38).  p0 = [Csmall][25][Cbig], p1 = [Cbig][25][Csmall];
+ * either output may be NULL. */
+int vp_pack_w5_f32(const float* w_ref, float* p0, float* p1, int Csmall, int Cbig, vp_stream stream);
+
+/* ---- 5x5 pad-2 convolution families (stride 1 or 2; big = stride * small) ------------------ */
+/* small[B,Hs,Ws,Cs] = act(bias + conv5(big[B,s*Hs,s*Ws,Cb]))
+ *   replaces nn.Conv2d fwd models/networks.py:27 (EncoderBlock), :100-103 (final conv + Sigmoid,
+ *   act = VP_ACT_SIGMOID) and nn.ConvTranspose2d's input gradient (autograd of :43). */
+int vp_conv5_gather_f32(const float* big, const float* w_p0, const float* bias, float* small_out,
+                        int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream);
+/* big[B,s*Hs,s*Ws,Cb] = convT5(small)  (sub-pixel phases, no zero insertion)
+ *   replaces nn.ConvTranspose2d fwd models/networks.py:43 (DecoderBlock) and nn.Conv2d's input
+ *   gradient (autograd of :27, :100). */
+int vp_conv5_scatter_f32(const float* small, const float* w_p1, float* big_out,
+                         int B, int Hs, int Ws, int Csmall, int Cbig, int stride, vp_stream stream);
+/* dW[Cs][Cb][5][5] (reference layout) = sum_pixels small (x) shifted big
+ *   replaces the weight gradient of both layer kinds (autograd of models/networks.py:27,:43,:100). */
+size_t vp_conv5_wgrad_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride);
+int vp_conv5_wgrad_f32(const float* big, const float* small, float* dw_ref,
+                       int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
+                       void* ws, size_t ws_bytes, vp_stream stream);
+
+/* ---- dense layers ------------------------------------------------------------------------ */
+/* C[m][n] = bias[n] + sum_k A(m,k) B(n,k) with element strides (sam,sak) / (sbn,sbk).
+ * mode 0: both operands k-contiguous (Linear fwd, models/networks.py:75-77,109)
+ * mode 1: A k-contiguous, B n-contiguous (Linear input gradient)
+ * mode 2: A m-contiguous, B n-contiguous (Linear weight gradient) */
+size_t vp_gemm_workspace_bytes(int M, int N, int K);
+int vp_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, long sbk,
+                float* C, int ldc, const float* bias, int M, int N, int K, int mode,
+                void* ws, size_t ws_bytes, vp_stream stream);
+/* out[c] = sum_r x[r][c]   (bias gradients) */
+size_t vp_colsum_workspace_bytes(int R, int C);
+int vp_colsum_f32(const float* x, float* out, int R, int C, void* ws, size_t ws_bytes, vp_stream stream);
+
+/* ---- BatchNorm (+ activation) over an [R][C] NHWC view (R = B*H*W, or B for BatchNorm1d) ---- */
+/* replaces nn.BatchNorm2d/1d(momentum=0.9) + F.relu  models/networks.py:16,28-29,40,44-45,66-67,89-90;
+ * also the norm/act vocabulary of models/blocks.py:19-30. */
+size_t vp_bn_workspace_bytes(int R, int C);
+/* batch statistics: mean[c], rstd[c] = 1/sqrt(biased_var+eps); if running_* != NULL they are
+ * updated in place: run = (1-momentum)*run + momentum*batch (unbiased var), torch semantics. */
+int vp_bn_stats_f32(const float* x, int R, int C, float eps, float momentum,
+                    float* mean, float* rstd, float* running_mean, float* running_var,
+                    void* ws, size_t ws_bytes, vp_stream stream);
+/* y = act(gamma*(x-mean)*rstd + beta); gamma/beta may be NULL (affine=False). */
+int vp_bn_act_fwd_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      float* y, int R, int C, int act, float slope, vp_stream stream);
+/* backward through act + BN.  batch_stats=1: training-mode formula (statistics depend on x);
+ * batch_stats=0: eval mode (mean/rstd constants).  dgamma/dbeta may be NULL.  dx may alias dy. */
+int vp_bn_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                      int R, int C, int act, float slope, int batch_stats,
+                      void* ws, size_t ws_bytes, vp_stream stream);
+/* plain activation (conv + bias + act blocks of models/blocks.py:24-30 with bn=None) */
+int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream);
+/* dx = dy * act'(.) evaluated from the OUTPUT y (relu/lrelu/tanh/sigmoid); dx may alias dy */
+int vp_act_bwd_from_y_f32(const float* y, const float* dy, float* dx, size_t n, int act, float slope, vp_stream stream);
+
+/* ---- latent: reparameterisation + KL -------------------------------------------------------- */
+/* z = eps*exp(0.5*logvar) + mu   (models/networks.py:228-231);
+ * kl[b] = -0.5*sum_j(1 + logvar - mu^2 - exp(logvar))  (models/networks.py:270); kl may be NULL */
+int vp_latent_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, float* kl,
+                      int B, int Z, vp_stream stream);
+/* dmu = dz + gkl[b]*mu ; dlogvar = dz*eps*0.5*exp(0.5*logvar) + gkl[b]*0.5*(exp(logvar)-1)
+ * dz may be NULL (KL term only); gkl is per-sample dL/dkl[b] (NULL = 0) */
+int vp_latent_bwd_f32(const float* mu, const float* logvar, const float* eps, const float* dz, const float* gkl,
+                      float gkl_scalar, float* dmu, float* dlogvar, int B, int Z, vp_stream stream);
+
+/* ---- per-pixel BCE ------------------------------------------------------------------------ */
+/* out[0] = sum_i -[t*max(log p,-100) + (1-t)*max(log(1-p),-100)]  (torch F.binary_cross_entropy,
+ * reduction='sum'; call form train_BE_font.py:107).  p and t may have different memory order only
+ * if the caller made them match. */
+size_t vp_reduce_workspace_bytes(size_t n);
+int vp_bce_sum_f32(const float* p, const float* t, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream);
+/* dp = g * (p - t) / max(p*(1-p), 1e-12)   (torch's BCE backward) ; g read from device scalar gptr * gscale */
+int vp_bce_bwd_f32(const float* p, const float* t, const float* gptr, float gscale, float* dp, size_t n, vp_stream stream);
+/* fused sigmoid+BCE backward on the logits: dlogit = gscale * (p - t) */
+int vp_bce_sigmoid_bwd_f32(const float* p, const float* t, float gscale, float* dlogit, size_t n, vp_stream stream);
+/* out[0] = sum x */
+int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream);
+
+/* ---- optimiser step on a flat arena (train_BE.py:62-64,131; train.py:136-140) --------------- */
+/* torch.optim.Adam semantics (no amsgrad, no weight decay); g is multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce). step is the 1-based step count. */
+int vp_adam_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                float eps, int step, float grad_scale, vp_stream stream);
+/* torch.optim.RMSprop semantics (alpha, eps; no momentum, not centered) */
+int vp_rmsprop_f32(float* p, const float* g, float* sq, size_t n, float lr, float alpha, float eps,
+                   float grad_scale, vp_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

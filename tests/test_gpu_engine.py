@@ -1,0 +1,107 @@
+"""GPU tests of the fused training step (vae_play_amd/engine.py): it must reproduce the golden
+reference vectors and be interchangeable with the autograd modules (same gradients), eagerly and
+when replayed from a captured hipGraph."""
+import pytest
+import torch
+
+from tests.util import NORTH_STAR_RTOL, assert_close, load_golden, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(C, S, z, B, kind="adam"):
+    import vae_play_amd as V
+    from vae_play_amd import engine, optim
+    from oracle import ref_cpu as O
+    L = O.iter_level_for(S)
+    p0 = O.init_params(C, z, L, seed=0)
+    vae = V.VAE(S, z, C, init_rule=False)
+    vae.load_state_dict(p0)
+    vae.to(DEV).train()
+    opt = (optim.Adam if kind == "adam" else optim.RMSprop)(vae.parameters(), lr=1e-4)
+    step = engine.FusedVAEStep(vae, opt, B, S, C)
+    return vae, opt, step, p0, L
+
+
+@pytest.mark.parametrize("name", ["step_32x32x1_z16_b4_adam", "step_64x64x3_z64_b2_adam", "step_128x128x3_z128_b2_adam"])
+def test_fused_step_against_reference_golden(name):
+    from oracle import ref_cpu as O
+    g = load_golden(name)
+    C, S, z, B = (int(g[k]) for k in ("meta_C", "meta_S", "meta_z", "meta_B"))
+    steps = int(g["meta_steps"])
+    vae, opt, fused, p0, L = build(C, S, z, B)
+    x, eps = O.synthetic_batch(B, C, S, z)
+    xd, epsd = x.to(DEV), eps.to(DEV)
+    names = [n for n, _ in vae.named_parameters()]
+    for step in range(1, steps + 1):
+        loss, recon, kl = fused.forward_backward(xd, epsd)
+        if step == 1:
+            tol = NORTH_STAR_RTOL
+            assert_close(fused.mu, t(g["mu"]), tol, "mu")
+            assert_close(fused.logvar, t(g["logvar"]), tol, "logvar")
+            assert_close(fused.z, t(g["z"]), tol, "z")
+            xt = fused.x_tilde.detach().cpu().contiguous()
+            assert_close(xt.flatten()[::7][:8192], t(g["x_tilde_stride7"]), tol, "x_tilde")
+            for k, v in (("loss", loss), ("recon", recon), ("kl", kl)):
+                assert abs(v.item() - g[k][0]) <= tol * abs(g[k][0]), f"{k}: {v.item()} vs {g[k][0]}"
+            params = dict(vae.named_parameters())
+            for n in names:
+                gr = params[n].grad.detach().cpu().contiguous()
+                l2 = g[f"grad_l2/{n}"][0]
+                assert abs(gr.double().pow(2).sum().sqrt().item() - l2) <= tol * l2 + 1e-12, f"grad l2 {n}"
+                idx = O.sample_indices(gr.numel())
+                d = (gr.flatten()[idx].double() - t(g[f"grad_samples/{n}"])).abs().max().item()
+                assert d <= tol * 30 * max(l2 / gr.numel() ** 0.5, 1e-12), f"grad samples {n}"
+            sd = vae.state_dict()
+            for k in g:
+                if k.startswith("bn/"):
+                    assert_close(sd[k[3:]].flatten()[:4096], t(g[k]).flatten(), tol, k)
+        opt.step()
+        params = dict(vae.named_parameters())
+        for n in names:
+            l2 = g[f"param{step}_l2/{n}"][0]
+            pv = params[n].detach().cpu().double()
+            assert abs(pv.pow(2).sum().sqrt().item() - l2) <= 1e-5 * l2 + 1e-9, f"param l2 step {step} {n}"
+    fused.sync_counters()
+    assert int(vae.encoder.conv[0].bn.num_batches_tracked) == steps
+
+
+def test_fused_step_equals_autograd_modules_and_graph_replay():
+    import vae_play_amd as V
+    from oracle import ref_cpu as O
+    C, S, z, B = 3, 32, 16, 8
+    vae, opt, fused, p0, L = build(C, S, z, B)
+    x, eps = O.synthetic_batch(B, C, S, z)
+    xd, epsd = x.to(DEV), eps.to(DEV)
+    sd0 = {k: v.clone() for k, v in vae.state_dict().items()}
+    # autograd path
+    opt.zero_grad()
+    xt, mu, lv = vae(xd, eps=epsd)
+    loss, _, _ = V.vae_loss(xd, xt, mu, lv)
+    loss.backward()
+    g_auto = opt.flat_grad.clone()
+    rm_auto = vae.decoder.conv[0].bn.running_mean.clone()
+    # fused eager
+    vae.load_state_dict(sd0)
+    opt.flat_grad.fill_(float("nan"))       # every gradient element must be overwritten
+    loss_f, _, _ = fused.forward_backward(xd, epsd)
+    g_fused = opt.flat_grad.clone()
+    used = torch.zeros_like(g_fused, dtype=torch.bool)
+    for p, o in zip(opt.arena.params, opt.arena.offsets):
+        used[o:o + p.numel()] = True
+    assert torch.isfinite(g_fused[used]).all(), "a gradient tensor was not written by the fused step"
+    assert_close(g_fused[used], g_auto[used], 1e-5, "fused vs autograd grads")
+    assert abs(loss_f.item() - loss.item()) <= 1e-6 * abs(loss.item())
+    assert_close(vae.decoder.conv[0].bn.running_mean, rm_auto, 1e-6, "running stats")
+    # graph replay: same numbers, BN buffers untouched by the capture itself
+    vae.load_state_dict(sd0)
+    fused.capture()
+    assert torch.equal(vae.decoder.conv[0].bn.running_mean, sd0["decoder.conv.0.bn.running_mean"])
+    opt.flat_grad.fill_(float("nan"))
+    loss_g, _, _ = fused.forward_backward(xd, epsd)
+    assert torch.equal(opt.flat_grad[used], g_fused[used]), "graph replay differs from eager launch"
+    assert loss_g.item() == loss_f.item()
+    # full step runs (single process: no collective)
+    fused.step(xd, epsd)
+    assert torch.isfinite(opt.flat_param).all()

@@ -1,0 +1,84 @@
+"""ctypes binding of libvaeplay_hip.so (C ABI: include/vaeplay_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, the
+product path raises.  PyTorch is used only for device memory (``data_ptr()``) and the
+current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvaeplay_hip.so")
+
+P = c_void_p  # device pointers / stream
+
+# name -> (restype, argtypes); mirrors include/vaeplay_hip.h one to one
+SIGNATURES = {
+    "vp_abi_version": (c_int, []),
+    "vp_last_error": (c_char_p, []),
+    "vp_nchw_to_nhwc_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "vp_nhwc_to_nchw_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "vp_pack_w5_f32": (c_int, [P, P, P, c_int, c_int, P]),
+    "vp_conv5_gather_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_conv5_scatter_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_conv5_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "vp_conv5_wgrad_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "vp_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vp_gemm_f32": (c_int, [P, c_long, c_long, P, c_long, c_long, P, c_int, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "vp_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vp_colsum_f32": (c_int, [P, P, c_int, c_int, P, c_size_t, P]),
+    "vp_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vp_bn_stats_f32": (c_int, [P, c_int, c_int, c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_bn_act_fwd_f32": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
+    "vp_bn_act_bwd_f32": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, c_size_t, P]),
+    "vp_act_fwd_f32": (c_int, [P, P, c_size_t, c_int, c_float, P]),
+    "vp_act_bwd_from_y_f32": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
+    "vp_latent_fwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    "vp_latent_bwd_f32": (c_int, [P, P, P, P, P, c_float, P, P, c_int, c_int, P]),
+    "vp_reduce_workspace_bytes": (c_size_t, [c_size_t]),
+    "vp_bce_sum_f32": (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
+    "vp_bce_bwd_f32": (c_int, [P, P, P, c_float, P, c_size_t, P]),
+    "vp_bce_sigmoid_bwd_f32": (c_int, [P, P, c_float, P, c_size_t, P]),
+    "vp_sum_f32": (c_int, [P, c_size_t, P, P, c_size_t, P]),
+    "vp_adam_f32": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    "vp_rmsprop_f32": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
+}
+
+_lib = None
+
+
+class VaePlayHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raise (never fall back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VaePlayHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C vae_play_amd/csrc`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().vp_last_error()
+        raise VaePlayHipError(f"{what or 'vaeplay_hip'} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

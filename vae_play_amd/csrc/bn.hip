@@ -1,0 +1,316 @@
+// BatchNorm (+ activation) over an [R][C] NHWC view.  HBM-bound: every pass streams the
+// activation once with 16-B loads; reductions are per-thread fp32 partials -> LDS tree ->
+// per-chunk slab -> fp64 finalize (deterministic, no atomics).
+//   R = B*H*W for BatchNorm2d, R = B for BatchNorm1d (models/networks.py:16,40,66,89).
+#include "common.h"
+#include "problems.h"
+
+namespace vp {
+
+constexpr int BN_TX = 16;   // float4 lanes across channels  (64 channels per block)
+constexpr int BN_TY = 16;   // row lanes
+constexpr int BN_CH = BN_TX * 4;
+
+struct BnGrid { int chunks_r, chunks_c, rows_per_chunk; };
+
+inline BnGrid bn_grid(int R, int C) {
+  BnGrid g;
+  g.chunks_c = (C + BN_CH - 1) / BN_CH;
+  int want = 2048 / g.chunks_c;
+  if (want < 1) want = 1;
+  int maxr = (R + 31) / 32;   // at least ~32 rows per chunk
+  if (maxr < 1) maxr = 1;
+  g.chunks_r = want < maxr ? want : maxr;
+  g.rows_per_chunk = (R + g.chunks_r - 1) / g.chunks_r;
+  g.chunks_r = (R + g.rows_per_chunk - 1) / g.rows_per_chunk;
+  return g;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  switch (act) {
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_LRELU: return v > 0.f ? v : v * slope;
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+// derivative of act at pre-activation value u
+__device__ __forceinline__ float act_grad_pre(float u, int act, float slope) {
+  switch (act) {
+    case ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case ACT_LRELU: return u > 0.f ? 1.f : slope;
+    case ACT_TANH: { float t = tanhf(u); return 1.f - t * t; }
+    case ACT_SIGMOID: { float s = 1.f / (1.f + __expf(-u)); return s * (1.f - s); }
+    default: return 1.f;
+  }
+}
+
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dy * act'(gamma*xhat+beta).
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ part, int R, int C, int rows_per_chunk,
+                                                         int act, float slope) {
+  __shared__ float sh[2][BN_TY][BN_CH + 4];
+  const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
+  const int c = blockIdx.y * BN_CH + tx * 4;
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(R, r0 + rows_per_chunk);
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = (C % 4 == 0);
+  float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = c + j < C;
+    mu[j] = (MODE == 1 && ok) ? mean[c + j] : 0.f;
+    rs[j] = (MODE == 1 && ok) ? rstd[c + j] : 0.f;
+    ga[j] = (MODE == 1 && ok && gamma) ? gamma[c + j] : 1.f;
+    be[j] = (MODE == 1 && ok && beta) ? beta[c + j] : 0.f;
+  }
+  if (c < C) {
+    for (int r = r0 + ty; r < r1; r += BN_TY) {
+      float xv[4], gv[4];
+      const size_t off = (size_t)r * C + c;
+      if (vec) {
+        vp_f32x4 t = *reinterpret_cast<const vp_f32x4*>(x + off);
+        xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3];
+        if (MODE == 1) {
+          vp_f32x4 d = *reinterpret_cast<const vp_f32x4*>(dy + off);
+          gv[0] = d[0]; gv[1] = d[1]; gv[2] = d[2]; gv[3] = d[3];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xv[j] = (c + j < C) ? x[off + j] : 0.f;
+          if (MODE == 1) gv[j] = (c + j < C) ? dy[off + j] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (MODE == 0) {
+          s0[j] += xv[j];
+          s1[j] += xv[j] * xv[j];
+        } else {
+          const float xh = (xv[j] - mu[j]) * rs[j];
+          const float g = gv[j] * act_grad_pre(ga[j] * xh + be[j], act, slope);
+          s0[j] += g;
+          s1[j] += g * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sh[0][ty][tx * 4 + j] = s0[j];
+    sh[1][ty][tx * 4 + j] = s1[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * BN_CH) {
+    const int which = threadIdx.x / BN_CH, cc = threadIdx.x % BN_CH;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_TY; ++k) s += sh[which][k][cc];
+    const int cg = blockIdx.y * BN_CH + cc;
+    if (cg < C) part[((size_t)which * gridDim.x + blockIdx.x) * C + cg] = s;
+  }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nchunk, int R, int C, float eps, float momentum,
+                                      float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rm,
+                                      float* __restrict__ rv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    s += (double)part[(size_t)k * C + c];
+    q += (double)part[((size_t)nchunk + k) * C + c];
+  }
+  const double m = s / R;
+  double var = q / R - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
+  if (rv) {
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nchunk, int C, float* __restrict__ sum_g,
+                                    float* __restrict__ sum_gx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    s += (double)part[(size_t)k * C + c];
+    q += (double)part[((size_t)nchunk + k) * C + c];
+  }
+  sum_g[c] = (float)s;
+  sum_gx[c] = (float)q;
+  if (dbeta) dbeta[c] = (float)s;
+  if (dgamma) dgamma[c] = (float)q;
+}
+
+// y = act(x*scale + shift)
+__global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y, size_t n,
+                                                         int C, int act, float slope) {
+  const bool vec = (C % 4 == 0);
+  if (vec) {
+    const size_t n4 = n / 4;
+    const int C4 = C / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+      const int c = (int)(i % C4) * 4;
+      vp_f32x4 v = *reinterpret_cast<const vp_f32x4*>(x + i * 4);
+      vp_f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = rstd[c + j] * (gamma ? gamma[c + j] : 1.f);
+        const float sf = (beta ? beta[c + j] : 0.f) - mean[c + j] * sc;
+        o[j] = act_apply(v[j] * sc + sf, act, slope);
+      }
+      *reinterpret_cast<vp_f32x4*>(y + i * 4) = o;
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+      const int c = (int)(i % C);
+      const float sc = rstd[c] * (gamma ? gamma[c] : 1.f);
+      const float sf = (beta ? beta[c] : 0.f) - mean[c] * sc;
+      y[i] = act_apply(x[i] * sc + sf, act, slope);
+    }
+  }
+}
+
+// dx = gamma*rstd*(g - [batch_stats]*(sum_g + xhat*sum_gx)/R)
+__global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict__ x, const float* dy,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                                                         float* dx, size_t n, int C, float invR, int act,
+                                                         float slope) {
+  const bool vec = (C % 4 == 0);
+  const size_t cnt = vec ? n / 4 : n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
+    if (vec) {
+      const int c = (int)(i % (C / 4)) * 4;
+      vp_f32x4 xv = *reinterpret_cast<const vp_f32x4*>(x + i * 4);
+      vp_f32x4 dv = *reinterpret_cast<const vp_f32x4*>(dy + i * 4);
+      vp_f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ga = gamma ? gamma[c + j] : 1.f, be = beta ? beta[c + j] : 0.f;
+        const float xh = (xv[j] - mean[c + j]) * rstd[c + j];
+        const float g = dv[j] * act_grad_pre(ga * xh + be, act, slope);
+        o[j] = ga * rstd[c + j] * (g - (sum_g[c + j] + xh * sum_gx[c + j]) * invR);
+      }
+      *reinterpret_cast<vp_f32x4*>(dx + i * 4) = o;
+    } else {
+      const int c = (int)(i % C);
+      const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+      const float xh = (x[i] - mean[c]) * rstd[c];
+      const float g = dy[i] * act_grad_pre(ga * xh + be, act, slope);
+      dx[i] = ga * rstd[c] * (g - (sum_g[c] + xh * sum_gx[c]) * invR);
+    }
+  }
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float slope) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = act_apply(x[i], act, slope);
+}
+__global__ void act_bwd_from_y_kernel(const float* __restrict__ y, const float* dy, float* dx,
+                                      size_t n, int act, float slope) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = y[i];
+    float d;
+    switch (act) {
+      case ACT_RELU: d = v > 0.f ? 1.f : 0.f; break;
+      case ACT_LRELU: d = v > 0.f ? 1.f : slope; break;
+      case ACT_TANH: d = 1.f - v * v; break;
+      case ACT_SIGMOID: d = v * (1.f - v); break;
+      default: d = 1.f;
+    }
+    dx[i] = dy[i] * d;
+  }
+}
+
+inline size_t bn_ws_floats(int R, int C) {
+  BnGrid g = bn_grid(R, C);
+  return (size_t)2 * g.chunks_r * C + (size_t)2 * C;   // partial slabs + (sum_g, sum_gx)
+}
+
+}  // namespace vp
+
+using namespace vp;
+
+extern "C" {
+
+size_t vp_bn_workspace_bytes(int R, int C) { return bn_ws_floats(R, C) * sizeof(float); }
+
+int vp_bn_stats_f32(const float* x, int R, int C, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                    float* running_var, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(x && mean && rstd && ws && R > 0 && C > 0, "vp_bn_stats_f32: bad arguments");
+  if (ws_bytes < vp_bn_workspace_bytes(R, C)) return fail(VP_ERR_WORKSPACE, "vp_bn_stats_f32: workspace too small");
+  BnGrid g = bn_grid(R, C);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)ws;
+  hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks_r, g.chunks_c), dim3(256), 0, s, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, R, C,
+                     g.rows_per_chunk, 0, 0.f);
+  int rc = check_launch("vp_bn_stats_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)part, g.chunks_r, R, C, eps,
+                     momentum, mean, rstd, running_mean, running_var);
+  return check_launch("vp_bn_stats_f32(final)");
+}
+
+int vp_bn_act_fwd_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                      int R, int C, int act, float slope, vp_stream stream) {
+  VP_REQUIRE(x && mean && rstd && y && R > 0 && C > 0, "vp_bn_act_fwd_f32: bad arguments");
+  const size_t n = (size_t)R * C;
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
+                     beta, y, n, C, act, slope);
+  return check_launch("vp_bn_act_fwd_f32");
+}
+
+int vp_bn_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, float* dx, float* dgamma, float* dbeta, int R, int C, int act, float slope,
+                      int batch_stats, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(x && dy && mean && rstd && dx && ws && R > 0 && C > 0, "vp_bn_act_bwd_f32: bad arguments");
+  if (ws_bytes < vp_bn_workspace_bytes(R, C)) return fail(VP_ERR_WORKSPACE, "vp_bn_act_bwd_f32: workspace too small");
+  BnGrid g = bn_grid(R, C);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)ws;
+  float* sum_g = part + (size_t)2 * g.chunks_r * C;
+  float* sum_gx = sum_g + C;
+  hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks_r, g.chunks_c), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta, part,
+                     R, C, g.rows_per_chunk, act, slope);
+  int rc = check_launch("vp_bn_act_bwd_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)part, g.chunks_r, C, sum_g, sum_gx,
+                     dgamma, dbeta);
+  rc = check_launch("vp_bn_act_bwd_f32(final)");
+  if (rc) return rc;
+  const size_t n = (size_t)R * C;
+  const float invR = batch_stats ? 1.f / (float)R : 0.f;
+  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
+                     (const float*)sum_g, (const float*)sum_gx, dx, n, C, invR, act, slope);
+  return check_launch("vp_bn_act_bwd_f32(apply)");
+}
+
+int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream) {
+  VP_REQUIRE(x && y && n > 0, "vp_act_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, act, slope);
+  return check_launch("vp_act_fwd_f32");
+}
+
+int vp_act_bwd_from_y_f32(const float* y, const float* dy, float* dx, size_t n, int act, float slope, vp_stream stream) {
+  VP_REQUIRE(y && dy && dx && n > 0, "vp_act_bwd_from_y_f32: bad arguments");
+  hipLaunchKernelGGL(act_bwd_from_y_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n, act, slope);
+  return check_launch("vp_act_bwd_from_y_f32");
+}
+}

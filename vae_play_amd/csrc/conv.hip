@@ -1,0 +1,96 @@
+// 5x5 convolution families on the MFMA implicit-GEMM kernel (igemm.h) + weight packing + wgrad reduce.
+#include "common.h"
+#include "igemm.h"
+
+namespace vp {
+
+// w_ref[Cs][Cb][25] -> p0[Cs][25][Cb], p1[Cb][25][Cs].  One thread per element of w_ref; reads
+// are coalesced, the two scattered writes are absorbed by L2 (weights are <= 26 MB).
+__global__ void pack_w5_kernel(const float* __restrict__ w, float* __restrict__ p0, float* __restrict__ p1, int Cs, int Cb) {
+  const size_t n = (size_t)Cs * Cb * kTaps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % kTaps);
+    const size_t sc = i / kTaps;
+    const int cb = (int)(sc % Cb), cs = (int)(sc / Cb);
+    const float v = w[i];
+    if (p0) p0[((size_t)cs * kTaps + t) * Cb + cb] = v;
+    if (p1) p1[((size_t)cb * kTaps + t) * Cs + cs] = v;
+  }
+}
+
+// dw_ref[cs][cb][tap] = sum_split slab[split][tap][cs][cb]; thread per (tap, cs, cb): coalesced
+// slab reads, stride-25 writes (small tensor).
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cs, int Cb, int nsplit) {
+  const size_t per = (size_t)kTaps * Cs * Cb;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+    const int cb = (int)(i % Cb);
+    const size_t r = i / Cb;
+    const int cs = (int)(r % Cs), t = (int)(r / Cs);
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += slab[(size_t)sp * per + i];
+    dw[((size_t)cs * Cb + cb) * kTaps + t] = s;
+  }
+}
+
+}  // namespace vp
+
+using namespace vp;
+
+extern "C" {
+
+int vp_pack_w5_f32(const float* w_ref, float* p0, float* p1, int Csmall, int Cbig, vp_stream stream) {
+  VP_REQUIRE(w_ref && (p0 || p1) && Csmall > 0 && Cbig > 0, "vp_pack_w5_f32: bad arguments");
+  const size_t n = (size_t)Csmall * Cbig * kTaps;
+  hipLaunchKernelGGL(pack_w5_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w_ref, p0, p1, Csmall, Cbig);
+  return check_launch("vp_pack_w5_f32");
+}
+
+int vp_conv5_gather_f32(const float* big, const float* w_p0, const float* bias, float* small_out, int B, int Hs, int Ws,
+                        int Cbig, int Csmall, int stride, int act, vp_stream stream) {
+  VP_REQUIRE(big && w_p0 && small_out, "vp_conv5_gather_f32: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0, "vp_conv5_gather_f32: bad shape");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_gather_f32: stride must be 1 or 2");
+  VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv5_gather_f32: epilogue supports none|sigmoid");
+  VP_REQUIRE((long)B * Hs * Ws * stride * stride < (1L << 30), "vp_conv5_gather_f32: pixel count overflows int");
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  ProbF p = make_probF(big, w_p0, bias, small_out, g, act);
+  launch_igemm(p, p.M, p.N, 1, (hipStream_t)stream);
+  return check_launch("vp_conv5_gather_f32");
+}
+
+int vp_conv5_scatter_f32(const float* small, const float* w_p1, float* big_out, int B, int Hs, int Ws, int Csmall,
+                         int Cbig, int stride, vp_stream stream) {
+  VP_REQUIRE(small && w_p1 && big_out, "vp_conv5_scatter_f32: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0, "vp_conv5_scatter_f32: bad shape");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_scatter_f32: stride must be 1 or 2");
+  VP_REQUIRE((long)B * Hs * Ws * stride * stride < (1L << 30), "vp_conv5_scatter_f32: pixel count overflows int");
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  ProbT p = make_probT(small, w_p1, big_out, g);
+  launch_igemm(p, p.M, p.N, stride * stride, (hipStream_t)stream);
+  return check_launch("vp_conv5_scatter_f32");
+}
+
+size_t vp_conv5_wgrad_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  return wgrad_slab_floats(g, wgrad_nsplit(g)) * sizeof(float);
+}
+
+int vp_conv5_wgrad_f32(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Cbig, int Csmall,
+                       int stride, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(big && small && dw_ref && ws, "vp_conv5_wgrad_f32: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0, "vp_conv5_wgrad_f32: bad shape");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_wgrad_f32: stride must be 1 or 2");
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  const int ns = wgrad_nsplit(g);
+  if (ws_bytes < wgrad_slab_floats(g, ns) * sizeof(float))
+    return fail(VP_ERR_WORKSPACE, "vp_conv5_wgrad_f32: workspace %zu < %zu", ws_bytes, wgrad_slab_floats(g, ns) * sizeof(float));
+  ProbW p = make_probW(big, small, (float*)ws, g, ns);
+  launch_igemm(p, p.M, p.N, kTaps * ns, (hipStream_t)stream);
+  int rc = check_launch("vp_conv5_wgrad_f32(main)");
+  if (rc) return rc;
+  const size_t per = (size_t)kTaps * Csmall * Cbig;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(per, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dw_ref,
+                     Csmall, Cbig, ns);
+  return check_launch("vp_conv5_wgrad_f32(reduce)");
+}
+}

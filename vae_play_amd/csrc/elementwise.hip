@@ -1,0 +1,266 @@
+// HBM-bound glue kernels: layout transposes, latent (reparameterise + KL), per-pixel BCE with
+// wavefront reductions, and the fused flat-arena optimiser steps.
+#include "common.h"
+#include "problems.h"
+
+namespace vp {
+
+// out[b][c][r] = in[b][r][c]  (32x32 LDS tile, +1 pad: conflict-free for ds_read_b32 columns)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const size_t base = (size_t)blockIdx.z * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = in[base + (size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[base + (size_t)c * rows + r] = tile[threadIdx.x][j];
+  }
+}
+
+inline int launch_transpose(const float* in, float* out, int B, int rows, int cols, hipStream_t s, const char* what) {
+  VP_REQUIRE(in && out && B > 0 && rows > 0 && cols > 0, "%s: bad arguments", what);
+  VP_REQUIRE(B <= 65535, "%s: batch > 65535", what);
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, B);
+  VP_REQUIRE(grid.y <= 65535, "%s: too many row tiles", what);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, out, rows, cols);
+  return check_launch(what);
+}
+
+// one wavefront per sample: z = eps*exp(0.5*lv)+mu ; kl[b] = -0.5*sum(1 + lv - mu^2 - exp(lv))
+__global__ void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                                  float* __restrict__ z, float* __restrict__ kl, int Z) {
+  const int b = blockIdx.x;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < Z; j += 64) {
+    const size_t i = (size_t)b * Z + j;
+    const float m = mu[i], l = lv[i];
+    z[i] = eps[i] * expf(0.5f * l) + m;
+    acc += -expf(l) - m * m + l + 1.f;
+  }
+  acc = wave_sum(acc);
+  if (kl && threadIdx.x == 0) kl[b] = -0.5f * acc;
+}
+
+__global__ void latent_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                                  const float* __restrict__ dz, const float* __restrict__ gkl, float gkl_scalar,
+                                  float* __restrict__ dmu, float* __restrict__ dlv, int B, int Z) {
+  const size_t n = (size_t)B * Z;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / Z);
+    const float g = (gkl ? gkl[b] : 0.f) + gkl_scalar;
+    const float m = mu[i], l = lv[i];
+    const float d = dz ? dz[i] : 0.f;
+    dmu[i] = d + g * m;
+    dlv[i] = d * eps[i] * 0.5f * expf(0.5f * l) + g * 0.5f * (expf(l) - 1.f);
+  }
+}
+
+// MODE 0: BCE term  MODE 1: plain sum
+template <int MODE>
+__global__ void __launch_bounds__(256) reduce_partial_kernel(const float* __restrict__ p, const float* __restrict__ t, size_t n,
+                                                             float* __restrict__ part) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    vp_f32x4 pv = *reinterpret_cast<const vp_f32x4*>(p + i * 4);
+    if (MODE == 0) {
+      vp_f32x4 tv = *reinterpret_cast<const vp_f32x4*>(t + i * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lp = fmaxf(logf(pv[j]), -100.f), lq = fmaxf(logf(1.f - pv[j]), -100.f);
+        acc -= tv[j] * lp + (1.f - tv[j]) * lq;
+      }
+    } else {
+      acc += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail
+    const size_t i = n4 * 4 + threadIdx.x;
+    if (MODE == 0) {
+      const float lp = fmaxf(logf(p[i]), -100.f), lq = fmaxf(logf(1.f - p[i]), -100.f);
+      acc -= t[i] * lp + (1.f - t[i]) * lq;
+    } else {
+      acc += p[i];
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ void reduce_final_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) acc += (double)part[i];
+  acc = wave_sum_d(acc);
+  if (threadIdx.x == 0) out[0] = (float)acc;
+}
+
+inline unsigned reduce_blocks(size_t n) { return grid_for(n / 4 + 1, 256, 1024); }
+
+__global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ gptr,
+                               float gscale, float* __restrict__ dp, size_t n) {
+  const float g = (gptr ? gptr[0] : 1.f) * gscale;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    dp[i] = g * (pv - t[i]) / fmaxf((1.f - pv) * pv, 1e-12f);
+  }
+}
+
+__global__ void bce_sigmoid_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, float gscale,
+                                       float* __restrict__ dl, size_t n) {
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    vp_f32x4 pv = *reinterpret_cast<const vp_f32x4*>(p + i * 4);
+    vp_f32x4 tv = *reinterpret_cast<const vp_f32x4*>(t + i * 4);
+    vp_f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = gscale * (pv[j] - tv[j]);
+    *reinterpret_cast<vp_f32x4*>(dl + i * 4) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    dl[i] = gscale * (p[i] - t[i]);
+  }
+}
+
+// torch.optim.Adam (single-tensor form): m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g;
+// denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float eps, float step_size, float bc2_sqrt,
+                                                   float grad_scale) {
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    vp_f32x4 pv = *reinterpret_cast<vp_f32x4*>(p + i * 4);
+    vp_f32x4 gv = *reinterpret_cast<const vp_f32x4*>(g + i * 4);
+    vp_f32x4 mv = *reinterpret_cast<vp_f32x4*>(m + i * 4);
+    vp_f32x4 vv = *reinterpret_cast<vp_f32x4*>(v + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gv[j] * grad_scale;
+      mv[j] = mv[j] + one_minus_b1 * (gr - mv[j]);
+      vv[j] = vv[j] * b2 + one_minus_b2 * gr * gr;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pv[j] = pv[j] - step_size * (mv[j] / denom);
+    }
+    *reinterpret_cast<vp_f32x4*>(p + i * 4) = pv;
+    *reinterpret_cast<vp_f32x4*>(m + i * 4) = mv;
+    *reinterpret_cast<vp_f32x4*>(v + i * 4) = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    const float gr = g[i] * grad_scale;
+    const float mm = m[i] + one_minus_b1 * (gr - m[i]);
+    const float vv = v[i] * b2 + one_minus_b2 * gr * gr;
+    m[i] = mm; v[i] = vv;
+    p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+  }
+}
+
+// torch.optim.RMSprop: sq = alpha*sq + (1-alpha)*g*g; p -= lr * g / (sqrt(sq) + eps)
+__global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                      size_t n, float lr, float alpha, float one_minus_alpha, float eps,
+                                                      float grad_scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gr = g[i] * grad_scale;
+    const float s = sq[i] * alpha + one_minus_alpha * gr * gr;
+    sq[i] = s;
+    p[i] = p[i] - lr * (gr / (sqrtf(s) + eps));
+  }
+}
+
+}  // namespace vp
+
+using namespace vp;
+
+extern "C" {
+
+int vp_abi_version(void) { return 1; }
+const char* vp_last_error(void) { return err_buf(); }
+
+int vp_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, vp_stream stream) {
+  return launch_transpose(in, out, B, C, H * W, (hipStream_t)stream, "vp_nchw_to_nhwc_f32");
+}
+int vp_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, vp_stream stream) {
+  return launch_transpose(in, out, B, H * W, C, (hipStream_t)stream, "vp_nhwc_to_nchw_f32");
+}
+
+int vp_latent_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, float* kl, int B, int Z, vp_stream stream) {
+  VP_REQUIRE(mu && logvar && eps && z && B > 0 && Z > 0, "vp_latent_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mu, logvar, eps, z, kl, Z);
+  return check_launch("vp_latent_fwd_f32");
+}
+
+int vp_latent_bwd_f32(const float* mu, const float* logvar, const float* eps, const float* dz, const float* gkl,
+                      float gkl_scalar, float* dmu, float* dlogvar, int B, int Z, vp_stream stream) {
+  VP_REQUIRE(mu && logvar && eps && dmu && dlogvar && B > 0 && Z > 0, "vp_latent_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for((size_t)B * Z, 256)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, dz,
+                     gkl, gkl_scalar, dmu, dlogvar, B, Z);
+  return check_launch("vp_latent_bwd_f32");
+}
+
+size_t vp_reduce_workspace_bytes(size_t n) { return (size_t)reduce_blocks(n) * sizeof(float); }
+
+int vp_bce_sum_f32(const float* p, const float* t, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(p && t && out && ws && n > 0, "vp_bce_sum_f32: bad arguments");
+  const unsigned nb = reduce_blocks(n);
+  if (ws_bytes < nb * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_bce_sum_f32: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((reduce_partial_kernel<0>), dim3(nb), dim3(256), 0, s, p, t, n, (float*)ws);
+  int rc = check_launch("vp_bce_sum_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, (int)nb, out);
+  return check_launch("vp_bce_sum_f32(final)");
+}
+
+int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(x && out && ws && n > 0, "vp_sum_f32: bad arguments");
+  const unsigned nb = reduce_blocks(n);
+  if (ws_bytes < nb * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_sum_f32: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((reduce_partial_kernel<1>), dim3(nb), dim3(256), 0, s, x, (const float*)nullptr, n, (float*)ws);
+  int rc = check_launch("vp_sum_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, (int)nb, out);
+  return check_launch("vp_sum_f32(final)");
+}
+
+int vp_bce_bwd_f32(const float* p, const float* t, const float* gptr, float gscale, float* dp, size_t n, vp_stream stream) {
+  VP_REQUIRE(p && t && dp && n > 0, "vp_bce_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, t, gptr, gscale, dp, n);
+  return check_launch("vp_bce_bwd_f32");
+}
+
+int vp_bce_sigmoid_bwd_f32(const float* p, const float* t, float gscale, float* dlogit, size_t n, vp_stream stream) {
+  VP_REQUIRE(p && t && dlogit && n > 0, "vp_bce_sigmoid_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(bce_sigmoid_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, p, t, gscale, dlogit, n);
+  return check_launch("vp_bce_sigmoid_bwd_f32");
+}
+
+int vp_adam_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                float grad_scale, vp_stream stream) {
+  VP_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vp_adam_f32: bad arguments");
+  VP_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "vp_adam_f32: arena must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                     1.f - beta1, beta2, 1.f - beta2, eps, step_size, bc2_sqrt, grad_scale);
+  return check_launch("vp_adam_f32");
+}
+
+int vp_rmsprop_f32(float* p, const float* g, float* sq, size_t n, float lr, float alpha, float eps, float grad_scale,
+                   vp_stream stream) {
+  VP_REQUIRE(p && g && sq && n > 0, "vp_rmsprop_f32: bad arguments");
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p, g, sq, n, lr, alpha,
+                     1.f - alpha, eps, grad_scale);
+  return check_launch("vp_rmsprop_f32");
+}
+}

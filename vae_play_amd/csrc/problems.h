@@ -1,0 +1,445 @@
+// Implicit-GEMM problem descriptors for the 5x5 convolution families and the plain GEMMs.
+//
+// Every hot contraction of the VAE step is expressed as  C[m][n] = sum_k A(m,k) * B(n,k)
+// where A/B are *accessors* over NHWC activations and packed weights -- no im2col buffer is
+// ever materialised in HBM.  The same accessor code is compiled for the device (igemm.h, MFMA
+// kernel) and for the host (tests/host_emul, a naive triple loop) so that the index math is
+// validated on CPU against torch before it ever runs on a GPU.
+//
+// Vocabulary ("big"/"small"): a 5x5, pad-2 convolution with stride s relates a big image
+// (Hb = s*Hs) and a small image (Hs) by  big[s*h - 2 + r] <-> small[h],  r in 0..4.
+//   reference weight tensor  W[small_ch][big_ch][r][q]   (Conv2d: (Cout,Cin,5,5);
+//                                                          ConvTranspose2d: (Cin,Cout,5,5))
+//   F family ("gather")  : small = f(big)   Conv2d fwd, ConvTranspose2d dgrad
+//   T family ("scatter") : big   = f(small) ConvTranspose2d fwd, Conv2d dgrad (phase-decomposed,
+//                                           no zero insertion: 9/6/6/4 taps at stride 2)
+//   W family ("wgrad")   : dW    = f(big, small)
+// Reference: models/networks.py:14 (Conv2d k5 s2 p2), :38 (ConvTranspose2d k5 s2 p2 op1),
+//            :100-103 (Conv2d k5 s1 p2 + bias + Sigmoid).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define VP_HD __host__ __device__ __forceinline__
+#else
+#define VP_HD inline
+#endif
+
+typedef float vp_f32x4 __attribute__((ext_vector_type(4)));
+
+namespace vp {
+
+constexpr int kTaps = 25;
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
+
+VP_HD vp_f32x4 zero4() { vp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// 16-byte load.  Callers guarantee 16-B alignment whenever they take the vector path (the
+// host sets the vec flags from strides/channel counts), so the device gets one dwordx4 load.
+VP_HD vp_f32x4 ld4(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *reinterpret_cast<const vp_f32x4*>(p);
+#else
+  vp_f32x4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+#endif
+}
+
+struct ConvGeom {
+  int B, Hs, Ws, Hb, Wb, Cs, Cb, stride;
+};
+
+// --------------------------------------------------------------------------------------------
+// F family: out_small[b,hs,ws,n] = bias[n] + sum_{r,q,c} big[b, s*hs-2+r, s*ws-2+q, c] * wp0[n][r*5+q][c]
+//   M = B*Hs*Ws, N = Cs, K = 25*Cb.  Both operands are "MK" (k contiguous).
+// --------------------------------------------------------------------------------------------
+struct ProbF {
+  static constexpr bool A_KM = false, B_KM = false;
+  const float* big;
+  const float* w;     // packed P0: [Cs][25][Cb]
+  const float* bias;  // nullable
+  float* out;         // [B,Hs,Ws,Cs]
+  ConvGeom g;
+  int act;
+  int M, N, K;
+  int vec;  // Cb % 4 == 0
+
+  struct ZCtx { int k_begin, k_end; };
+  struct ARow { int pix_base, h0, w0, valid; };
+  struct BRow { int off, valid; };
+
+  VP_HD void z_setup(int, ZCtx& z) const { z.k_begin = 0; z.k_end = K; }
+
+  VP_HD ARow a_row(int m, const ZCtx&) const {
+    ARow r;
+    r.valid = m < M;
+    int mm = r.valid ? m : 0;
+    int b = mm / (g.Hs * g.Ws);
+    int rem = mm - b * (g.Hs * g.Ws);
+    int hs = rem / g.Ws;
+    int ws = rem - hs * g.Ws;
+    r.pix_base = b * g.Hb * g.Wb;
+    r.h0 = g.stride * hs - 2;
+    r.w0 = g.stride * ws - 2;
+    return r;
+  }
+  VP_HD float a_elem(const ARow& r, int k) const {
+    if (!r.valid || k >= K) return 0.f;
+    int tap = k / g.Cb, c = k - tap * g.Cb;
+    int rr = tap / 5, qq = tap - rr * 5;
+    int h = r.h0 + rr, w = r.w0 + qq;
+    if (h < 0 || h >= g.Hb || w < 0 || w >= g.Wb) return 0.f;
+    return big[(size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c];
+  }
+  VP_HD vp_f32x4 a_load(const ARow& r, int k, const ZCtx&) const {
+    if (vec) {
+      if (!r.valid || k >= K) return zero4();
+      int tap = k / g.Cb, c = k - tap * g.Cb;
+      int rr = tap / 5, qq = tap - rr * 5;
+      int h = r.h0 + rr, w = r.w0 + qq;
+      if (h < 0 || h >= g.Hb || w < 0 || w >= g.Wb) return zero4();
+      return ld4(big + (size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c);
+    }
+    vp_f32x4 v = {a_elem(r, k), a_elem(r, k + 1), a_elem(r, k + 2), a_elem(r, k + 3)};
+    return v;
+  }
+  VP_HD BRow b_row(int n, const ZCtx&) const {
+    BRow r;
+    r.valid = n < N;
+    r.off = (r.valid ? n : 0) * K;
+    return r;
+  }
+  VP_HD vp_f32x4 b_load(const BRow& r, int k, const ZCtx&) const {
+    if (!r.valid) return zero4();
+    if (vec && k + 3 < K) return ld4(w + (size_t)r.off + k);
+    vp_f32x4 v = zero4();
+    for (int j = 0; j < 4; ++j)
+      if (k + j < K) v[j] = w[(size_t)r.off + k + j];
+    return v;
+  }
+  VP_HD void store(int m, int n, float v, const ZCtx&) const {
+    if (m >= M || n >= N) return;
+    if (bias) v += bias[n];
+    if (act == ACT_SIGMOID) v = 1.f / (1.f + __builtin_expf(-v));
+    out[(size_t)m * N + n] = v;
+  }
+};
+
+// --------------------------------------------------------------------------------------------
+// T family: out_big[b, s*q+ph, s*p+pw, n] = sum_{r',q',c} small[b, q+d0-r', p+d0-q', c] * wp1[n][(ph+s*r')*5+(pw+s*q')][c]
+//   one GEMM per output phase z = ph*s+pw; taps_h = ceil((5-ph)/s); d0 = 2/s.
+//   M = B*Hs*Ws, N = Cb, K = taps_h*taps_w*Cs.
+// --------------------------------------------------------------------------------------------
+struct ProbT {
+  static constexpr bool A_KM = false, B_KM = false;
+  const float* small;
+  const float* w;  // packed P1: [Cb][25][Cs]
+  float* out;      // [B,Hb,Wb,Cb]
+  ConvGeom g;
+  int M, N;
+  int vec;  // Cs % 4 == 0
+
+  struct ZCtx { int k_begin, k_end, ph, pw, th, tw; };
+  struct ARow { int pix_base, q, p, valid; };
+  struct BRow { int off, valid; };
+
+  VP_HD void z_setup(int zi, ZCtx& z) const {
+    int s = g.stride;
+    z.ph = zi / s;
+    z.pw = zi - z.ph * s;
+    z.th = (5 - z.ph + s - 1) / s;
+    z.tw = (5 - z.pw + s - 1) / s;
+    z.k_begin = 0;
+    z.k_end = z.th * z.tw * g.Cs;
+  }
+  VP_HD ARow a_row(int m, const ZCtx&) const {
+    ARow r;
+    r.valid = m < M;
+    int mm = r.valid ? m : 0;
+    int b = mm / (g.Hs * g.Ws);
+    int rem = mm - b * (g.Hs * g.Ws);
+    r.q = rem / g.Ws;
+    r.p = rem - r.q * g.Ws;
+    r.pix_base = b * g.Hs * g.Ws;
+    return r;
+  }
+  VP_HD float a_elem(const ARow& r, int k, const ZCtx& z) const {
+    if (!r.valid || k >= z.k_end) return 0.f;
+    int t = k / g.Cs, c = k - t * g.Cs;
+    int rp = t / z.tw, qp = t - rp * z.tw;
+    int d0 = 2 / g.stride;
+    int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+    if (h < 0 || h >= g.Hs || w_ < 0 || w_ >= g.Ws) return 0.f;
+    return small[(size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c];
+  }
+  VP_HD vp_f32x4 a_load(const ARow& r, int k, const ZCtx& z) const {
+    if (vec) {
+      if (!r.valid || k >= z.k_end) return zero4();
+      int t = k / g.Cs, c = k - t * g.Cs;
+      int rp = t / z.tw, qp = t - rp * z.tw;
+      int d0 = 2 / g.stride;
+      int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+      if (h < 0 || h >= g.Hs || w_ < 0 || w_ >= g.Ws) return zero4();
+      return ld4(small + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c);
+    }
+    vp_f32x4 v = {a_elem(r, k, z), a_elem(r, k + 1, z), a_elem(r, k + 2, z), a_elem(r, k + 3, z)};
+    return v;
+  }
+  VP_HD BRow b_row(int n, const ZCtx&) const {
+    BRow r;
+    r.valid = n < N;
+    r.off = (r.valid ? n : 0) * kTaps * g.Cs;
+    return r;
+  }
+  VP_HD float b_elem(const BRow& r, int k, const ZCtx& z) const {
+    if (!r.valid || k >= z.k_end) return 0.f;
+    int t = k / g.Cs, c = k - t * g.Cs;
+    int rp = t / z.tw, qp = t - rp * z.tw;
+    int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+    return w[(size_t)r.off + tap * g.Cs + c];
+  }
+  VP_HD vp_f32x4 b_load(const BRow& r, int k, const ZCtx& z) const {
+    if (vec) {
+      if (!r.valid || k >= z.k_end) return zero4();
+      int t = k / g.Cs, c = k - t * g.Cs;
+      int rp = t / z.tw, qp = t - rp * z.tw;
+      int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+      return ld4(w + (size_t)r.off + tap * g.Cs + c);
+    }
+    vp_f32x4 v = {b_elem(r, k, z), b_elem(r, k + 1, z), b_elem(r, k + 2, z), b_elem(r, k + 3, z)};
+    return v;
+  }
+  VP_HD void store(int m, int n, float v, const ZCtx& z) const {
+    if (m >= M || n >= N) return;
+    int b = m / (g.Hs * g.Ws);
+    int rem = m - b * (g.Hs * g.Ws);
+    int q = rem / g.Ws, p = rem - q * g.Ws;
+    int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
+    out[((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n] = v;
+  }
+};
+
+// --------------------------------------------------------------------------------------------
+// W family: slab[split][tap][m=cs][n=cb] = sum_{pixels in split} small[pix][cs] * big[shift_tap(pix)][cb]
+//   z = tap*nsplit + split.  M = Cs, N = Cb, K = B*Hs*Ws.  Both operands "KM" (k = pixel is the slow index).
+//   A second pass (wgrad_reduce) sums the splits and writes the reference layout dW[cs][cb][tap].
+// --------------------------------------------------------------------------------------------
+struct ProbW {
+  static constexpr bool A_KM = true, B_KM = true;
+  const float* big;
+  const float* small;
+  float* slab;  // [nsplit][25][Cs][Cb]
+  ConvGeom g;
+  int M, N, K;
+  int nsplit, k_per_split;
+  int vec_a, vec_b;  // Cs % 4 == 0, Cb % 4 == 0
+
+  struct ZCtx { int k_begin, k_end, rr, qq, tap, split; };
+
+  VP_HD void z_setup(int zi, ZCtx& z) const {
+    z.tap = zi / nsplit;
+    z.split = zi - z.tap * nsplit;
+    z.rr = z.tap / 5;
+    z.qq = z.tap - z.rr * 5;
+    z.k_begin = z.split * k_per_split;
+    int e = z.k_begin + k_per_split;
+    z.k_end = e < K ? e : K;
+  }
+  // A(k = pixel, m .. m+3) = small[pixel][m..m+3]
+  VP_HD vp_f32x4 a_load_km(int k, int m, const ZCtx& z) const {
+    if (k >= z.k_end) return zero4();
+    const float* p = small + (size_t)k * g.Cs;
+    if (vec_a && m + 3 < M) return ld4(p + m);
+    vp_f32x4 v = zero4();
+    for (int j = 0; j < 4; ++j)
+      if (m + j < M) v[j] = p[m + j];
+    return v;
+  }
+  // B(k = pixel, n .. n+3) = big[b, s*hs-2+r, s*ws-2+q][n..n+3]
+  VP_HD vp_f32x4 b_load_km(int k, int n, const ZCtx& z) const {
+    if (k >= z.k_end) return zero4();
+    int b = k / (g.Hs * g.Ws);
+    int rem = k - b * (g.Hs * g.Ws);
+    int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+    int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
+    if (h < 0 || h >= g.Hb || w_ < 0 || w_ >= g.Wb) return zero4();
+    const float* p = big + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb;
+    if (vec_b && n + 3 < N) return ld4(p + n);
+    vp_f32x4 v = zero4();
+    for (int j = 0; j < 4; ++j)
+      if (n + j < N) v[j] = p[n + j];
+    return v;
+  }
+  VP_HD void store(int m, int n, float v, const ZCtx& z) const {
+    if (m >= M || n >= N) return;
+    slab[(((size_t)z.split * kTaps + z.tap) * M + m) * N + n] = v;
+  }
+};
+
+// --------------------------------------------------------------------------------------------
+// Plain GEMM  C[m][n] = sum_k A(m,k) B(n,k) (+bias[n]) with arbitrary element strides.
+//   template flags pick the LDS image per operand: MK (k contiguous in memory) or KM (m contiguous).
+//   Linear fwd   y = x W^T      : A = x  (MK), B = W  (MK)
+//   Linear dgrad dx = dy W      : A = dy (MK), B = W  (KM: B(n,k) = W[k][n])
+//   Linear wgrad dW = dy^T x    : A = dy (KM: A(m,k) = dy[k][m]), B = x (KM)
+//   Reference: nn.Linear at models/networks.py:65,69-70,88.
+//   Split-K: z = split; partials go to slab[split][M][N], summed (+bias) by gemm_reduce.
+// --------------------------------------------------------------------------------------------
+template <bool AKM, bool BKM>
+struct ProbG {
+  static constexpr bool A_KM = AKM, B_KM = BKM;
+  const float* A;
+  const float* Bm;
+  float* C;           // direct output (nsplit == 1) or slab base
+  const float* bias;  // only applied when nsplit == 1
+  int M, N, K;
+  long sam, sak, sbn, sbk;  // element strides
+  int ldc;
+  int nsplit, k_per_split;
+  int vec_a, vec_b;  // contiguous-dim stride == 1, other stride % 4 == 0, 16B-aligned base
+
+  struct ZCtx { int k_begin, k_end, split; };
+  struct ARow { long off; int valid; };
+  struct BRow { long off; int valid; };
+
+  VP_HD void z_setup(int zi, ZCtx& z) const {
+    z.split = zi;
+    z.k_begin = zi * k_per_split;
+    int e = z.k_begin + k_per_split;
+    z.k_end = e < K ? e : K;
+  }
+  VP_HD ARow a_row(int m, const ZCtx&) const { ARow r; r.valid = m < M; r.off = (long)(r.valid ? m : 0) * sam; return r; }
+  VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (long)(r.valid ? n : 0) * sbn; return r; }
+  VP_HD vp_f32x4 a_load(const ARow& r, int k, const ZCtx& z) const {
+    if (!r.valid || k >= z.k_end) return zero4();
+    if (vec_a && k + 3 < z.k_end) return ld4(A + r.off + k);
+    vp_f32x4 v = zero4();
+    for (int j = 0; j < 4; ++j)
+      if (k + j < z.k_end) v[j] = A[r.off + (long)(k + j) * sak];
+    return v;
+  }
+  VP_HD vp_f32x4 b_load(const BRow& r, int k, const ZCtx& z) const {
+    if (!r.valid || k >= z.k_end) return zero4();
+    if (vec_b && k + 3 < z.k_end) return ld4(Bm + r.off + k);
+    vp_f32x4 v = zero4();
+    for (int j = 0; j < 4; ++j)
+      if (k + j < z.k_end) v[j] = Bm[r.off + (long)(k + j) * sbk];
+    return v;
+  }
+  VP_HD vp_f32x4 a_load_km(int k, int m, const ZCtx& z) const {
+    if (k >= z.k_end) return zero4();
+    const float* p = A + (long)k * sak;
+    if (vec_a && m + 3 < M) return ld4(p + m);
+    vp_f32x4 v = zero4();
+    for (int j = 0; j < 4; ++j)
+      if (m + j < M) v[j] = p[(long)(m + j) * sam];
+    return v;
+  }
+  VP_HD vp_f32x4 b_load_km(int k, int n, const ZCtx& z) const {
+    if (k >= z.k_end) return zero4();
+    const float* p = Bm + (long)k * sbk;
+    if (vec_b && n + 3 < N) return ld4(p + n);
+    vp_f32x4 v = zero4();
+    for (int j = 0; j < 4; ++j)
+      if (n + j < N) v[j] = p[(long)(n + j) * sbn];
+    return v;
+  }
+  VP_HD void store(int m, int n, float v, const ZCtx& z) const {
+    if (m >= M || n >= N) return;
+    if (nsplit == 1) {
+      if (bias) v += bias[n];
+      C[(size_t)m * ldc + n] = v;
+    } else {
+      C[((size_t)z.split * M + m) * N + n] = v;
+    }
+  }
+};
+
+}  // namespace vp
+
+// ---------------------------------------------------------------------------------------------
+// host-side builders (shared by the C ABI in conv.hip / gemm.hip and by tests/host_emul)
+// ---------------------------------------------------------------------------------------------
+namespace vp {
+
+inline ConvGeom make_geom(int B, int Hs, int Ws, int Cs, int Cb, int stride) {
+  ConvGeom g;
+  g.B = B; g.Hs = Hs; g.Ws = Ws; g.Hb = Hs * stride; g.Wb = Ws * stride;
+  g.Cs = Cs; g.Cb = Cb; g.stride = stride;
+  return g;
+}
+
+inline ProbF make_probF(const float* big, const float* wp0, const float* bias, float* out, const ConvGeom& g, int act) {
+  ProbF p;
+  p.big = big; p.w = wp0; p.bias = bias; p.out = out; p.g = g; p.act = act;
+  p.M = g.B * g.Hs * g.Ws; p.N = g.Cs; p.K = kTaps * g.Cb;
+  p.vec = (g.Cb % 4 == 0);
+  return p;
+}
+
+inline ProbT make_probT(const float* small, const float* wp1, float* out, const ConvGeom& g) {
+  ProbT p;
+  p.small = small; p.w = wp1; p.out = out; p.g = g;
+  p.M = g.B * g.Hs * g.Ws; p.N = g.Cb;
+  p.vec = (g.Cs % 4 == 0);
+  return p;
+}
+
+// K (= pixels) is split so that tiles * 25 taps * nsplit fills the 256 CUs a few times over.
+inline int wgrad_nsplit(const ConvGeom& g) {
+  long K = (long)g.B * g.Hs * g.Ws;
+  long tiles = ((g.Cs + 127) / 128) * (long)((g.Cb + 127) / 128) * kTaps;
+  long want = (768 + tiles - 1) / tiles;
+  long maxs = (K + 255) / 256;  // keep >= 8 K-tiles of 32 per split
+  long s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+inline ProbW make_probW(const float* big, const float* small, float* slab, const ConvGeom& g, int nsplit) {
+  ProbW p;
+  p.big = big; p.small = small; p.slab = slab; p.g = g;
+  p.M = g.Cs; p.N = g.Cb; p.K = g.B * g.Hs * g.Ws;
+  p.nsplit = nsplit;
+  int per = (p.K + nsplit - 1) / nsplit;
+  p.k_per_split = ((per + 31) / 32) * 32;
+  p.vec_a = (g.Cs % 4 == 0);
+  p.vec_b = (g.Cb % 4 == 0);
+  return p;
+}
+
+inline size_t wgrad_slab_floats(const ConvGeom& g, int nsplit) {
+  return (size_t)nsplit * kTaps * g.Cs * g.Cb;
+}
+
+inline int gemm_nsplit(long M, long N, long K) {
+  long bm = M <= 32 ? 32 : 128, bn = M <= 32 ? 128 : (N <= 32 ? 32 : 128);
+  long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  if (tiles >= 128) return 1;
+  long want = (512 + tiles - 1) / tiles;
+  long maxs = (K + 255) / 256;
+  long s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 128) s = 128;
+  return (int)s;
+}
+
+template <bool AKM, bool BKM>
+inline ProbG<AKM, BKM> make_probG(const float* A, long sam, long sak, const float* B, long sbn, long sbk,
+                                  float* C, int ldc, const float* bias, int M, int N, int K, int nsplit) {
+  ProbG<AKM, BKM> p;
+  p.A = A; p.Bm = B; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K;
+  p.sam = sam; p.sak = sak; p.sbn = sbn; p.sbk = sbk; p.ldc = ldc;
+  p.nsplit = nsplit;
+  int per = (K + nsplit - 1) / nsplit;
+  p.k_per_split = ((per + 31) / 32) * 32;
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  p.vec_a = AKM ? (sam == 1 && sak % 4 == 0 && al16(A)) : (sak == 1 && sam % 4 == 0 && al16(A));
+  p.vec_b = BKM ? (sbn == 1 && sbk % 4 == 0 && al16(B)) : (sbk == 1 && sbn % 4 == 0 && al16(B));
+  return p;
+}
+
+}  // namespace vp

@@ -1,0 +1,344 @@
+"""Fused VAE training step: the whole forward + loss + backward of SURVEY.md 3.3 as a fixed,
+pre-planned sequence of HIP kernel launches (no autograd, no per-step allocation).
+
+The plan is built once for a (model, batch size) pair:
+  * every activation / gradient buffer is preallocated NHWC in HBM and reused across steps;
+  * every parameter gradient is written exactly once, directly into the optimiser's flat gradient
+    arena (no zero_grad pass, no accumulate pass) -- the arena is then all-reduced once (RCCL) and
+    consumed by the fused optimiser kernel;
+  * the launch list is replayable and hipGraph-capturable (``capture()``), which removes the
+    launch-bound gaps between the ~150 small kernels of a step.
+
+It drives the same C-ABI entry points as the autograd modules and must produce identical
+gradients (tests/test_gpu_engine.py).  Reference path replaced: the loop body train_BE.py:54-64
+with the model/loss of models/networks.py (Encoder :72-78, reparameterize :228-231, Decoder
+:107-112, KL :270) and F.binary_cross_entropy.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, ops, parallel
+from .networks import VAE
+
+_ACT_RELU, _ACT_NONE, _ACT_SIGMOID = ops.ACT_RELU, ops.ACT_NONE, ops.ACT_SIGMOID
+
+
+class _Plan:
+    """A list of (c_function, argument list) with the stream slot patched at run time.
+    ``flops`` is the algorithmic FLOP count of a call (0 for bandwidth-bound glue); ``timers`` lets
+    bench.py bracket selected calls with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.calls: List[list] = []
+
+    def add(self, name: str, *args, flops: float = 0.0, tag: str = ""):
+        fn = getattr(_lib.load(), name)
+        a = list(args) + [None]  # last argument of every entry point is the stream
+        self.calls.append([name, fn, a, len(a) - 1, flops, tag])
+
+    def run(self, stream_ptr: int, timers: Optional[dict] = None):
+        s = c_void_p(stream_ptr)
+        for name, fn, a, slot, flops, tag in self.calls:
+            a[slot] = s
+            timed = timers is not None and name in timers["names"]
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = fn(*a)
+            if timed:
+                e1.record()
+                timers["events"].append((name, tag, flops, e0, e1))
+            if rc != 0:
+                _lib.check(rc, name)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+class FusedVAEStep:
+    """forward + loss + backward (+ all-reduce + optimiser) for a ``networks.VAE``.
+
+    ``optimizer`` must be a flat-arena optimiser from ``vae_play_amd.optim`` built over
+    ``vae.parameters()`` (its gradient arena receives the gradients).
+    """
+
+    def __init__(self, vae: VAE, optimizer, batch_size: int, img_size: int, channels: int, group=None):
+        self.vae, self.opt, self.B, self.S, self.C = vae, optimizer, batch_size, img_size, channels
+        self.Z, self.L = vae.z_size, vae.iter_level
+        self.group = group
+        self.world = torch.distributed.get_world_size(group) if torch.distributed.is_initialized() else 1
+        self.opt.grad_scale = 1.0 / self.world
+        dev = next(vae.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.VaePlayHipError("FusedVAEStep needs the model on the HIP device")
+        self.dev = dev
+        self._bufs: Dict[str, torch.Tensor] = {}
+        self._graph = None
+        self._build()
+
+    # ---- buffers ----------------------------------------------------------------------------
+    def _buf(self, name: str, *shape) -> torch.Tensor:
+        t = torch.empty(shape, dtype=torch.float32, device=self.dev)
+        self._bufs[name] = t
+        return t
+
+    def _ws(self, name: str, nbytes: int) -> torch.Tensor:
+        return self._buf(name, max(4, (nbytes + 3) // 4))
+
+    # ---- plan construction ------------------------------------------------------------------
+    def _build(self):
+        lib = _lib.load()
+        B, S, C, Z, L = self.B, self.S, self.C, self.Z, self.L
+        enc, dec = self.vae.encoder, self.vae.decoder
+        mom, eps_bn = 0.9, 1e-5
+        fwd, bwd = _Plan(), _Plan()
+        P = _ptr
+
+        def grad_of(p: torch.nn.Parameter) -> torch.Tensor:
+            if p.grad is None:
+                raise _lib.VaePlayHipError("parameter has no arena gradient; build the optimiser first")
+            return p.grad
+
+        def bn_block(tag, x_buf, R, Cn, bn_mod, y_buf):
+            """stats + fused normalise/ReLU; returns the saved (mean, rstd)."""
+            mean, rstd = self._buf(f"{tag}.mean", Cn), self._buf(f"{tag}.rstd", Cn)
+            ws = self._ws(f"{tag}.bnws", lib.vp_bn_workspace_bytes(R, Cn))
+            fwd.add("vp_bn_stats_f32", P(x_buf), R, Cn, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
+                    P(bn_mod.running_var), P(ws), ws.numel() * 4)
+            fwd.add("vp_bn_act_fwd_f32", P(x_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(y_buf), R, Cn,
+                    _ACT_RELU, 0.0)
+            return mean, rstd, ws
+
+        def bn_block_bwd(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws):
+            bwd.add("vp_bn_act_bwd_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(dx_buf),
+                    P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1, P(ws), ws.numel() * 4)
+
+        # ---------------- forward ----------------
+        self.x_nchw = self._buf("x_nchw", B, C, S, S)
+        self.eps = self._buf("eps", B, Z)
+        x_nhwc = self._buf("x_nhwc", B * S * S * C)
+        if C > 1:
+            fwd.add("vp_nchw_to_nhwc_f32", P(self.x_nchw), P(x_nhwc), B, C, S, S)
+        else:
+            x_nhwc = self.x_nchw  # identical memory order for one channel
+
+        enc_ch = [C] + [blk.conv.weight.shape[0] for blk in enc.conv]
+        sp = [S // (2 ** i) for i in range(L + 1)]
+        enc_in = [x_nhwc]
+        enc_rec = []
+        for i, blk in enumerate(enc.conv):
+            Cin, Cout, Hs = enc_ch[i], enc_ch[i + 1], sp[i + 1]
+            p0 = self._buf(f"enc{i}.p0", Cout * 25 * Cin)
+            p1 = self._buf(f"enc{i}.p1", Cin * 25 * Cout) if i > 0 else None
+            fwd.add("vp_pack_w5_f32", P(blk.conv.weight), P(p0), P(p1), Cout, Cin)
+            c = self._buf(f"enc{i}.c", B * Hs * Hs * Cout)
+            a = self._buf(f"enc{i}.a", B * Hs * Hs * Cout)
+            fwd.add("vp_conv5_gather_f32", P(enc_in[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
+                    flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"enc{i}.fwd")
+            mean, rstd, ws = bn_block(f"enc{i}", c, B * Hs * Hs, Cout, blk.bn, a)
+            enc_rec.append((blk, Cin, Cout, Hs, p1, c, mean, rstd, ws))
+            enc_in.append(a)
+        size = enc_ch[-1]
+        F0 = 64 * size
+        flat = self._buf("enc.flat", B * F0)
+        fwd.add("vp_nhwc_to_nchw_f32", P(enc_in[-1]), P(flat), B, size, 8, 8)
+        fc_lin, fc_bn = enc.fc[0], enc.fc[1]
+        h = self._buf("enc.h", B * 1024)
+        hb = self._buf("enc.hb", B * 1024)
+        ws_fc = self._ws("enc.fc.ws", lib.vp_gemm_workspace_bytes(B, 1024, F0))
+        fwd.add("vp_gemm_f32", P(flat), F0, 1, P(fc_lin.weight), F0, 1, P(h), 1024, None, B, 1024, F0, 0, P(ws_fc), ws_fc.numel() * 4)
+        h_mean, h_rstd, h_ws = bn_block("enc.fc", h, B, 1024, fc_bn, hb)
+        self.mu, self.logvar = self._buf("mu", B, Z), self._buf("logvar", B, Z)
+        ws_mu = self._ws("enc.mu.ws", lib.vp_gemm_workspace_bytes(B, Z, 1024))
+        for lin, out in ((enc.l_mu, self.mu), (enc.l_var, self.logvar)):
+            fwd.add("vp_gemm_f32", P(hb), 1024, 1, P(lin.weight), 1024, 1, P(out), Z, P(lin.bias), B, Z, 1024, 0, P(ws_mu), ws_mu.numel() * 4)
+        self.z, self.kl = self._buf("z", B, Z), self._buf("kl", B)
+        fwd.add("vp_latent_fwd_f32", P(self.mu), P(self.logvar), P(self.eps), P(self.z), P(self.kl), B, Z)
+
+        dfc_lin, dfc_bn = dec.fc[0], dec.fc[1]
+        dsize = dec._c0
+        F1 = 64 * dsize
+        d = self._buf("dec.d", B * F1)
+        db = self._buf("dec.db", B * F1)
+        ws_dfc = self._ws("dec.fc.ws", lib.vp_gemm_workspace_bytes(B, F1, Z))
+        fwd.add("vp_gemm_f32", P(self.z), Z, 1, P(dfc_lin.weight), Z, 1, P(d), F1, None, B, F1, Z, 0, P(ws_dfc), ws_dfc.numel() * 4)
+        d_mean, d_rstd, d_ws = bn_block("dec.fc", d, B, F1, dfc_bn, db)
+        dn = self._buf("dec.in", B * F1)
+        fwd.add("vp_nchw_to_nhwc_f32", P(db), P(dn), B, dsize, 8, 8)
+
+        dec_in = [dn]
+        dec_rec = []
+        dec_ch = [dsize] + [blk.conv.weight.shape[1] for blk in list(dec.conv)[:L]]
+        for i in range(L):
+            blk = dec.conv[i]
+            Cin, Cout, Hs = dec_ch[i], dec_ch[i + 1], 8 * (2 ** i)
+            p1 = self._buf(f"dec{i}.p1", Cout * 25 * Cin)   # T family: [Cbig=Cout][25][Csmall=Cin]
+            p0 = self._buf(f"dec{i}.p0", Cin * 25 * Cout)   # F family (dgrad): [Csmall=Cin][25][Cbig=Cout]
+            fwd.add("vp_pack_w5_f32", P(blk.conv.weight), P(p0), P(p1), Cin, Cout)
+            tbuf = self._buf(f"dec{i}.t", B * 4 * Hs * Hs * Cout)
+            u = self._buf(f"dec{i}.u", B * 4 * Hs * Hs * Cout)
+            fwd.add("vp_conv5_scatter_f32", P(dec_in[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
+                    flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"dec{i}.fwd")
+            mean, rstd, ws = bn_block(f"dec{i}", tbuf, B * 4 * Hs * Hs, Cout, blk.bn, u)
+            dec_rec.append((blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws))
+            dec_in.append(u)
+        fin = dec.conv[L][0]
+        Cf = dec_ch[-1]
+        fp0 = self._buf("fin.p0", C * 25 * Cf)
+        fp1 = self._buf("fin.p1", Cf * 25 * C)
+        fwd.add("vp_pack_w5_f32", P(fin.weight), P(fp0), P(fp1), C, Cf)
+        xt_nhwc = self._buf("xt_nhwc", B * S * S * C)
+        fwd.add("vp_conv5_gather_f32", P(dec_in[-1]), P(fp0), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, 1, _ACT_SIGMOID,
+                flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
+        self.recon = self._buf("recon", 1)
+        self.kl_sum = self._buf("kl_sum", 1)
+        n_pix = B * S * S * C
+        ws_red = self._ws("red.ws", lib.vp_reduce_workspace_bytes(n_pix))
+        fwd.add("vp_bce_sum_f32", P(xt_nhwc), P(x_nhwc), n_pix, P(self.recon), P(ws_red), ws_red.numel() * 4)
+        fwd.add("vp_sum_f32", P(self.kl), B, P(self.kl_sum), P(ws_red), ws_red.numel() * 4)
+        self.xt_nhwc = xt_nhwc
+        self.x_tilde = xt_nhwc.view(B, S, S, C).permute(0, 3, 1, 2)  # logical NCHW, channels_last memory
+
+        # ---------------- backward ----------------
+        inv_b = 1.0 / B
+        dlogit = self._buf("g.dlogit", n_pix)
+        bwd.add("vp_bce_sigmoid_bwd_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), n_pix)
+        ws_cs = self._ws("g.colsum.ws", lib.vp_colsum_workspace_bytes(B * S * S, C))
+        bwd.add("vp_colsum_f32", P(dlogit), P(grad_of(fin.bias)), B * S * S, C, P(ws_cs), ws_cs.numel() * 4)
+        ws_wg = self._ws("g.wgrad.ws", self._max_wgrad_ws(enc_rec, dec_rec, Cf))
+        bwd.add("vp_conv5_wgrad_f32", P(dec_in[-1]), P(dlogit), P(grad_of(fin.weight)), B, S, S, Cf, C, 1, P(ws_wg), ws_wg.numel() * 4,
+                flops=50.0 * B * S * S * Cf * C, tag="fin.wgrad")
+        # two ping-pong gradient buffers sized for the largest activation
+        big = max([B * F0, B * F1, n_pix] + [B * 4 * r[3] * r[3] * r[2] for r in dec_rec] + [B * r[3] * r[3] * r[2] for r in enc_rec]
+                  + [B * S * S * Cf])
+        gA, gB = self._buf("g.A", big), self._buf("g.B", big)
+        bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
+        cur, other = gA, gB
+        for i in range(L - 1, -1, -1):
+            blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws = dec_rec[i]
+            R = B * 4 * Hs * Hs
+            bn_block_bwd(tbuf, cur, other, R, Cout, blk.bn, mean, rstd, ws)          # other = d t_i
+            bwd.add("vp_conv5_wgrad_f32", P(other), P(dec_in[i]), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2,
+                    P(ws_wg), ws_wg.numel() * 4, flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"dec{i}.wgrad")
+            bwd.add("vp_conv5_gather_f32", P(other), P(p0), None, P(cur), B, Hs, Hs, Cout, Cin, 2, _ACT_NONE,
+                    flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"dec{i}.dgrad")  # cur = d input_i
+        bwd.add("vp_nhwc_to_nchw_f32", P(cur), P(other), B, dsize, 8, 8)                # other = d db  (B, F1)
+        bn_block_bwd(d, other, cur, B, F1, dfc_bn, d_mean, d_rstd, d_ws)                # cur = d d
+        ws_g1 = self._ws("g.gemm1.ws", max(lib.vp_gemm_workspace_bytes(F1, Z, B), lib.vp_gemm_workspace_bytes(B, Z, F1),
+                                            lib.vp_gemm_workspace_bytes(1024, F0, B), lib.vp_gemm_workspace_bytes(B, F0, 1024),
+                                            lib.vp_gemm_workspace_bytes(Z, 1024, B), lib.vp_gemm_workspace_bytes(B, 1024, Z)))
+        wsn = ws_g1.numel() * 4
+        bwd.add("vp_gemm_f32", P(cur), 1, F1, P(self.z), 1, Z, P(grad_of(dfc_lin.weight)), Z, None, F1, Z, B, 2, P(ws_g1), wsn)
+        dz = self._buf("g.dz", B, Z)
+        bwd.add("vp_gemm_f32", P(cur), F1, 1, P(dfc_lin.weight), 1, Z, P(dz), Z, None, B, Z, F1, 1, P(ws_g1), wsn)
+        dmu, dlv = self._buf("g.dmu", B, Z), self._buf("g.dlv", B, Z)
+        bwd.add("vp_latent_bwd_f32", P(self.mu), P(self.logvar), P(self.eps), P(dz), None, inv_b, P(dmu), P(dlv), B, Z)
+        ws_cs2 = self._ws("g.colsum2.ws", lib.vp_colsum_workspace_bytes(B, Z))
+        dhb_a, dhb_b = self._buf("g.dhb_a", B * 1024), self._buf("g.dhb_b", B * 1024)
+        for lin, dsrc, dst in ((enc.l_mu, dmu, dhb_a), (enc.l_var, dlv, dhb_b)):
+            bwd.add("vp_gemm_f32", P(dsrc), 1, Z, P(hb), 1, 1024, P(grad_of(lin.weight)), 1024, None, Z, 1024, B, 2, P(ws_g1), wsn)
+            bwd.add("vp_colsum_f32", P(dsrc), P(grad_of(lin.bias)), B, Z, P(ws_cs2), ws_cs2.numel() * 4)
+            bwd.add("vp_gemm_f32", P(dsrc), Z, 1, P(lin.weight), 1, 1024, P(dst), 1024, None, B, 1024, Z, 1, P(ws_g1), wsn)
+        self._dhb = (dhb_a, dhb_b)
+        bwd_b = _Plan()  # continues after the tiny add of the two head gradients
+        self._bwd_a = bwd
+        bwd = bwd_b
+        dh = self._buf("g.dh", B * 1024)
+
+        def bn_block_bwd2(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws):
+            bwd.add("vp_bn_act_bwd_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(dx_buf),
+                    P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1, P(ws), ws.numel() * 4)
+
+        bn_block_bwd2(h, dhb_a, dh, B, 1024, fc_bn, h_mean, h_rstd, h_ws)
+        bwd.add("vp_gemm_f32", P(dh), 1, 1024, P(flat), 1, F0, P(grad_of(fc_lin.weight)), F0, None, 1024, F0, B, 2, P(ws_g1), wsn)
+        bwd.add("vp_gemm_f32", P(dh), 1024, 1, P(fc_lin.weight), 1, F0, P(gA), F0, None, B, F0, 1024, 1, P(ws_g1), wsn)
+        bwd.add("vp_nchw_to_nhwc_f32", P(gA), P(gB), B, size, 8, 8)
+        cur, other = gB, gA
+        for i in range(L - 1, -1, -1):
+            blk, Cin, Cout, Hs, p1, c, mean, rstd, ws = enc_rec[i]
+            R = B * Hs * Hs
+            bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)               # other = d c_i
+            bwd.add("vp_conv5_wgrad_f32", P(enc_in[i]), P(other), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,
+                    P(ws_wg), ws_wg.numel() * 4, flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"enc{i}.wgrad")
+            if i > 0:
+                bwd.add("vp_conv5_scatter_f32", P(other), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
+                        flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"enc{i}.dgrad")  # cur = d a_{i-1}
+        self._fwd, self._bwd_b = fwd, bwd
+        self._bn_mods = [m for m in self.vae.modules() if hasattr(m, "num_batches_tracked")]
+
+    def _max_wgrad_ws(self, enc_rec, dec_rec, Cf) -> int:
+        lib = _lib.load()
+        B, S, C = self.B, self.S, self.C
+        n = lib.vp_conv5_wgrad_workspace_bytes(B, S, S, Cf, C, 1)
+        for blk, Cin, Cout, Hs, *_ in enc_rec:
+            n = max(n, lib.vp_conv5_wgrad_workspace_bytes(B, Hs, Hs, Cin, Cout, 2))
+        for blk, Cin, Cout, Hs, *_ in dec_rec:
+            n = max(n, lib.vp_conv5_wgrad_workspace_bytes(B, Hs, Hs, Cout, Cin, 2))
+        return n
+
+    # ---- execution ---------------------------------------------------------------------------
+    def _launch_all(self, timers: Optional[dict] = None):
+        s = torch.cuda.current_stream().cuda_stream
+        self._fwd.run(s, timers)
+        self._bwd_a.run(s, timers)
+        self._dhb[0].add_(self._dhb[1])          # d hb = dgrad(mu head) + dgrad(logvar head)  (B x 1024)
+        self._bwd_b.run(s, timers)
+        torch.add(self.recon, self.kl_sum, out=self._loss_num)
+
+    def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None):
+        """Gradients of (BCE_sum + KL_sum)/B land in the optimiser's flat gradient arena.
+        Returns (loss, recon, kl) as device scalars (no host sync).  ``timers`` =
+        {"names": set of entry points, "events": []} brackets those launches with HIP events
+        (eager mode only)."""
+        if not hasattr(self, "_loss_num"):
+            self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
+        self.x_nchw.copy_(x, non_blocking=True)
+        self.eps.copy_(eps, non_blocking=True)
+        if self._graph is not None and timers is None:
+            self._graph.replay()
+        else:
+            self._launch_all(timers)
+        # BatchNorm num_batches_tracked is advanced lazily in sync_counters()
+        self._steps_since_sync = getattr(self, "_steps_since_sync", 0) + 1
+        return self._loss_num / self.B, self.recon, self.kl_sum
+
+    def sync_counters(self):
+        """Advance BatchNorm ``num_batches_tracked`` buffers (bookkeeping only; kept off the hot path)."""
+        n = getattr(self, "_steps_since_sync", 0)
+        if n:
+            for m in self._bn_mods:
+                m.num_batches_tracked.add_(n)
+            self._steps_since_sync = 0
+
+    def step(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None):
+        """One full training step: fwd + loss + bwd, ONE all-reduce of the gradient arena, fused update."""
+        out = self.forward_backward(x, eps, timers)
+        parallel.allreduce_flat_grads(self.opt.flat_grad, self.group)
+        self.opt.step()
+        return out
+
+    def capture(self, warmup: int = 2):
+        """Capture forward+backward into a hipGraph (torch.cuda.CUDAGraph) and replay it from then on."""
+        if not hasattr(self, "_loss_num"):
+            self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
+        # warm-up and capture execute the step: keep the BatchNorm running buffers unchanged by them
+        saved = [(m, m.running_mean.clone(), m.running_var.clone()) for m in self._bn_mods]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._launch_all()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._launch_all()
+        self._graph = g
+        for m, rm, rv in saved:
+            m.running_mean.copy_(rm)
+            m.running_var.copy_(rv)
+        return g

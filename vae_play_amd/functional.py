@@ -1,0 +1,266 @@
+"""Autograd glue: each op of the VAE step as a torch.autograd.Function whose forward and
+backward are HIP kernels (via ops.py -> C ABI).  This is what lets the reference's
+``loss.backward()`` idiom (train_BE.py:63) work unchanged on the drop-in modules.
+
+Reference ops replaced (relative to the reference checkout):
+  conv5x5            nn.Conv2d(k5,p2,stride)                    models/networks.py:14,100
+  conv_transpose5x5  nn.ConvTranspose2d(k5,s2,p2,op1)           models/networks.py:38
+  batch_norm_act     nn.BatchNorm2d/1d + F.relu (+ blocks acts) models/networks.py:16,28-29,66-67; models/blocks.py:19-30
+  linear             nn.Linear                                  models/networks.py:65,69-70,88
+  reparameterize     VaeGan.reparameterize                      models/networks.py:228-231
+  kl_divergence      VaeGan.loss (kl term)                      models/networks.py:270
+  binary_cross_entropy  F.binary_cross_entropy                  train_BE_font.py:107
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import ACT_CODES, ACT_NONE, ACT_SIGMOID
+
+
+def _cl(t: torch.Tensor) -> torch.Tensor:
+    return ops.channels_last(t)
+
+
+class _Conv5(Function):
+    """small = act(bias + conv5x5(big)); weight (Csmall, Cbig, 5, 5) = nn.Conv2d layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride: int, act: int):
+        x = _cl(x)
+        p0, _ = ops.pack_w5(weight, True, False)
+        y = ops.conv5_gather(x, p0, bias, stride, act)
+        ctx.stride, ctx.act, ctx.has_bias = stride, act, bias is not None
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _cl(dy)
+        if ctx.act != ACT_NONE:
+            dy = ops.act_bwd_from_y(y, dy, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            _, p1 = ops.pack_w5(weight, False, True)
+            dx = ops.conv5_scatter(dy, p1, ctx.stride)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv5_wgrad(x, dy, ctx.stride)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            B, C, H, W = dy.shape
+            db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C))
+        return dx, dw, db, None, None
+
+
+class _ConvT5(Function):
+    """big = convT5x5(small), stride 2, padding 2, output_padding 1; weight (Csmall, Cbig, 5, 5)
+    = nn.ConvTranspose2d layout (in_channels first)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride: int):
+        x = _cl(x)
+        _, p1 = ops.pack_w5(weight, False, True)
+        y = ops.conv5_scatter(x, p1, stride)
+        ctx.stride = stride
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _cl(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            p0, _ = ops.pack_w5(weight, True, False)
+            dx = ops.conv5_gather(dy, p0, None, ctx.stride, ACT_NONE)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv5_wgrad(dy, x, ctx.stride)
+        return dx, dw, None
+
+
+class _BatchNormAct(Function):
+    """y = act(BN(x)); x is (B,C,H,W) channels_last or (B,F).  Training mode uses batch statistics
+    and updates the running buffers in place with torch's momentum semantics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training: bool, momentum: float, eps: float,
+                act: int, slope: float):
+        x = _cl(x) if x.dim() == 4 else x.contiguous()
+        if training:
+            mean, rstd = ops.bn_stats(x, eps, momentum, running_mean, running_var)
+        else:
+            mean = running_mean
+            rstd = torch.rsqrt(running_var + eps)
+        y = ops.bn_act_fwd(x, mean, rstd, gamma, beta, act, slope)
+        ctx.act, ctx.slope, ctx.training = act, slope, training
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        dy = _cl(dy) if dy.dim() == 4 else dy.contiguous()
+        need_affine = gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx, dgamma, dbeta = ops.bn_act_bwd(x, dy, mean, rstd, gamma, beta, ctx.act, ctx.slope, ctx.training, need_affine)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        y = ops.linear_fwd(x, weight, bias)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_dgrad(dy, weight)
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(dy, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy)
+        return dx, dw, db
+
+
+class _FlattenNCHW(Function):
+    """(B,C,H,W) channels_last -> (B, C*H*W) in the reference's (C,H,W) flatten order
+    (``ten.view(len(ten), -1)``, models/networks.py:74) via the HIP transpose."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        ctx.shape = x.shape
+        return ops.nhwc_to_nchw(x).reshape(x.shape[0], -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        return ops.nchw_to_nhwc(dy.contiguous().view(B, C, H, W))
+
+
+class _UnflattenNCHW(Function):
+    """(B, C*H*W) -> (B,C,H,W) channels_last (``ten.view(len(ten), -1, 8, 8)``, models/networks.py:110)."""
+
+    @staticmethod
+    def forward(ctx, x, C: int, H: int, W: int):
+        B = x.shape[0]
+        return ops.nchw_to_nhwc(x.contiguous().view(B, C, H, W))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _cl(dy)
+        return ops.nhwc_to_nchw(dy).reshape(dy.shape[0], -1), None, None, None
+
+
+class _Reparam(Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        z, _ = ops.latent_fwd(mu, logvar, eps, want_kl=False)
+        ctx.save_for_backward(mu, logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        mu, logvar, eps = ctx.saved_tensors
+        dmu, dlv = ops.latent_bwd(mu, logvar, eps, dz, None, 0.0)
+        return dmu, dlv, None
+
+
+class _KL(Function):
+    """kl[b] = -0.5 * sum_j(1 + logvar - mu^2 - exp(logvar))."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        zeros = torch.zeros_like(mu)
+        _, kl = ops.latent_fwd(mu, logvar, zeros, want_kl=True)
+        ctx.save_for_backward(mu, logvar, zeros)
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        mu, logvar, zeros = ctx.saved_tensors
+        dmu, dlv = ops.latent_bwd(mu, logvar, zeros, None, gkl, 0.0)
+        return dmu, dlv
+
+
+class _BCESum(Function):
+    @staticmethod
+    def forward(ctx, p, t):
+        if p.dim() == 4:
+            p, t = _cl(p), _cl(t)
+        else:
+            p, t = p.contiguous(), t.contiguous()
+        out = ops.bce_sum(p, t)
+        ctx.save_for_backward(p, t)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        return ops.bce_bwd(p, t, g.reshape(1).contiguous(), 1.0), None
+
+
+# ---- public functional API ----------------------------------------------------------------------
+def conv5x5(x, weight, bias=None, stride: int = 2, act: Optional[str] = None):
+    return _Conv5.apply(x, weight, bias, stride, ACT_CODES[act])
+
+
+def conv_transpose5x5(x, weight, stride: int = 2):
+    return _ConvT5.apply(x, weight, stride)
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, momentum: float = 0.1, eps: float = 1e-5,
+                   act: Optional[str] = "relu", slope: float = 0.0):
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, ACT_CODES[act], slope)
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+def flatten_nchw(x):
+    return _FlattenNCHW.apply(x)
+
+
+def unflatten_nchw(x, C: int, H: int, W: int):
+    return _UnflattenNCHW.apply(x, C, H, W)
+
+
+def reparameterize(mu, logvar, *, eps: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
+    """z = eps * exp(0.5*logvar) + mu (models/networks.py:228-231).  The reference draws eps with
+    ``normal_()``; here it may be injected (parity tests) or drawn with torch's device RNG."""
+    if eps is None:
+        eps = torch.randn(mu.shape, dtype=mu.dtype, device=mu.device, generator=generator)
+    return _Reparam.apply(mu, logvar, eps)
+
+
+def kl_divergence(mu, logvar):
+    """Per-sample KL of models/networks.py:270, shape (B,)."""
+    return _KL.apply(mu, logvar)
+
+
+def binary_cross_entropy(p, t, reduction: str = "sum"):
+    """F.binary_cross_entropy with torch's -100 log clamp; reduction 'sum' or 'mean'."""
+    s = _BCESum.apply(p, t)
+    if reduction == "sum":
+        return s
+    if reduction == "mean":
+        return s / p.numel()
+    raise ValueError("reduction must be 'sum' or 'mean'")
+
+
+def vae_loss(x, x_tilde, mu, logvar):
+    """(sum-BCE + sum-KL) / B -- the composed loss of SURVEY.md 3.3.  Returns (loss, recon, kl)."""
+    recon = binary_cross_entropy(x_tilde, x, "sum")
+    kl = kl_divergence(mu, logvar).sum()
+    return (recon + kl) / x.shape[0], recon, kl

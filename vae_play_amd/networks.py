@@ -1,0 +1,219 @@
+"""Drop-in VAE modules for kungyao/vae-play's ``models/networks.py`` backed by HIP kernels.
+
+Same constructor signatures, attribute names (``.size``, ``.conv``, ``.fc``, ``.l_mu``,
+``.l_var``), ``state_dict`` keys and default-init RNG consumption as the reference classes
+(so ``torch.manual_seed(s); Encoder(...)`` yields bit-identical weights), but ``forward``
+runs on libvaeplay_hip.so: NHWC implicit-GEMM convolutions on the MFMA units, fused
+BatchNorm+ReLU, HIP GEMMs for the dense layers.  Module I/O is logical NCHW fp32 like the
+reference; outputs are channels_last in memory.
+
+  EncoderBlock  <- models/networks.py:10-30      Encoder <- models/networks.py:49-81
+  DecoderBlock  <- models/networks.py:34-46      Decoder <- models/networks.py:84-115
+  reparameterize <- models/networks.py:228-231   init_parameters <- models/networks.py:214-226
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_hip
+
+BN_MOMENTUM = 0.9  # models/networks.py:16,40,66,89
+
+
+class Conv5x5Params(nn.Module):
+    """Parameter holder with nn.Conv2d / nn.ConvTranspose2d's weight layout, key names and
+    default initialisation (kaiming_uniform_(a=sqrt(5)) + fan-in-bounded bias), 5x5 kernel."""
+
+    def __init__(self, dim0: int, dim1: int, bias: bool, stride: int, transposed: bool):
+        super().__init__()
+        self.stride, self.transposed = stride, transposed
+        self.weight = nn.Parameter(torch.empty(dim0, dim1, 5, 5))
+        self.bias = nn.Parameter(torch.empty(dim1 if transposed else dim0)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            if fan_in != 0:
+                bound = 1 / math.sqrt(fan_in)
+                nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x: torch.Tensor, act: Optional[str] = None) -> torch.Tensor:
+        if self.transposed:
+            return F_hip.conv_transpose5x5(x, self.weight, self.stride)
+        return F_hip.conv5x5(x, self.weight, self.bias, self.stride, act)
+
+    def extra_repr(self) -> str:
+        kind = "ConvTranspose2d" if self.transposed else "Conv2d"
+        return f"{kind}{tuple(self.weight.shape)}, kernel 5, stride {self.stride}, padding 2 [HIP]"
+
+
+class LinearParams(nn.Module):
+    """nn.Linear's parameters / init, forward on the HIP GEMM."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F_hip.linear(x, self.weight, self.bias)
+
+    def extra_repr(self) -> str:
+        return f"in={self.in_features}, out={self.out_features}, bias={self.bias is not None} [HIP]"
+
+
+class BatchNormAct(nn.Module):
+    """BatchNorm2d/1d state (weight, bias, running_mean, running_var, num_batches_tracked) with a
+    fused activation; train()/eval() switch batch vs running statistics like torch."""
+
+    def __init__(self, num_features: int, momentum: float = 0.1, eps: float = 1e-5, act: Optional[str] = "relu",
+                 slope: float = 0.0):
+        super().__init__()
+        self.num_features, self.momentum, self.eps, self.act, self.slope = num_features, momentum, eps, act, slope
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return F_hip.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                    self.momentum, self.eps, self.act, self.slope)
+
+    def extra_repr(self) -> str:
+        return f"{self.num_features}, momentum={self.momentum}, eps={self.eps}, act={self.act} [HIP]"
+
+
+class EncoderBlock(nn.Module):
+    """conv5x5 s2 p2 (no bias) -> BatchNorm2d(momentum=0.9) -> ReLU."""
+
+    def __init__(self, channel_in, channel_out):
+        super().__init__()
+        self.conv = Conv5x5Params(channel_out, channel_in, bias=False, stride=2, transposed=False)
+        self.bn = BatchNormAct(channel_out, momentum=BN_MOMENTUM, act="relu")
+
+    def forward(self, ten, out=False, t=False):
+        ten = self.conv(ten)
+        if out:
+            return self.bn(ten), ten  # the pre-BN conv output is the discriminator's tap
+        return self.bn(ten)
+
+
+class DecoderBlock(nn.Module):
+    """convT5x5 s2 p2 op1 (no bias) -> BatchNorm2d(momentum=0.9) -> ReLU."""
+
+    def __init__(self, channel_in, channel_out):
+        super().__init__()
+        self.conv = Conv5x5Params(channel_in, channel_out, bias=False, stride=2, transposed=True)
+        self.bn = BatchNormAct(channel_out, momentum=BN_MOMENTUM, act="relu")
+
+    def forward(self, ten):
+        return self.bn(self.conv(ten))
+
+
+class Encoder(nn.Module):
+    def __init__(self, channel_in=3, z_size=128, iter_level=3):
+        super().__init__()
+        self.size = channel_in
+        layers = []
+        for i in range(iter_level):
+            cout = 64 if i == 0 else self.size * 2
+            layers.append(EncoderBlock(channel_in=self.size, channel_out=cout))
+            self.size = cout
+        self.conv = nn.Sequential(*layers)
+        # fc.0 / fc.1 carry the reference's keys; BN1d and ReLU run as one fused kernel
+        self.fc = nn.Sequential(LinearParams(8 * 8 * self.size, 1024, bias=False),
+                                BatchNormAct(1024, momentum=BN_MOMENTUM, act="relu"))
+        self.l_mu = LinearParams(1024, z_size)
+        self.l_var = LinearParams(1024, z_size)
+
+    def forward(self, ten):
+        ten = self.conv(ten)
+        ten = F_hip.flatten_nchw(ten)
+        ten = self.fc(ten)
+        return self.l_mu(ten), self.l_var(ten)
+
+
+class _SigmoidConv(nn.Sequential):
+    """Container whose child "0" holds the final conv's weight/bias (key ``conv.<L>.0.*``);
+    conv + bias + sigmoid run as one kernel (sigmoid in the MFMA epilogue)."""
+
+    def forward(self, x):
+        return self[0](x, act="sigmoid")
+
+
+class Decoder(nn.Module):
+    def __init__(self, z_size, size, channel_out=3, iter_level=3):
+        super().__init__()
+        self.fc = nn.Sequential(LinearParams(z_size, 8 * 8 * size, bias=False),
+                                BatchNormAct(8 * 8 * size, momentum=BN_MOMENTUM, act="relu"))
+        self.size = size
+        self._c0 = size
+        layers = [DecoderBlock(channel_in=self.size, channel_out=self.size)]
+        for _ in range(iter_level - 1):
+            layers.append(DecoderBlock(channel_in=self.size, channel_out=self.size // 2))
+            self.size = self.size // 2
+        layers.append(_SigmoidConv(Conv5x5Params(channel_out, self.size, bias=True, stride=1, transposed=False)))
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, ten):
+        ten = self.fc(ten)
+        ten = F_hip.unflatten_nchw(ten, self._c0, 8, 8)
+        return self.conv(ten)
+
+
+def reparameterize(mu, logvar, *, eps=None, generator=None):
+    """VaeGan.reparameterize (models/networks.py:228-231) with an injectable eps."""
+    return F_hip.reparameterize(mu, logvar, eps=eps, generator=generator)
+
+
+def init_parameters(*modules: nn.Module) -> None:
+    """VaeGan.init_parameters (models/networks.py:214-226): every conv / transposed-conv / linear
+    weight ~ U(+-1/sqrt(3 * prod(shape[1:]))), biases 0, in ``modules()`` order."""
+    for root in modules:
+        for m in root.modules():
+            if isinstance(m, (Conv5x5Params, LinearParams)):
+                if m.weight is not None and m.weight.requires_grad:
+                    scale = 1.0 / math.sqrt(float(torch.Size(m.weight.shape[1:]).numel()))
+                    scale /= math.sqrt(3)
+                    nn.init.uniform_(m.weight, -scale, scale)
+                if m.bias is not None and m.bias.requires_grad:
+                    nn.init.constant_(m.bias, 0.0)
+
+
+class VAE(nn.Module):
+    """Encoder -> reparameterize -> Decoder, the plain-VAE composition of SURVEY.md 3.3
+    (``iter_level = int(log2(img_size // 8))``, models/networks.py:204)."""
+
+    def __init__(self, img_size: int, z_size: int = 128, channels: int = 3, init_rule: bool = True):
+        super().__init__()
+        self.iter_level = int(math.log2(img_size // 8))
+        self.z_size = z_size
+        self.encoder = Encoder(channel_in=channels, z_size=z_size, iter_level=self.iter_level)
+        self.decoder = Decoder(z_size=z_size, size=self.encoder.size, channel_out=channels, iter_level=self.iter_level)
+        if init_rule:
+            init_parameters(self)
+
+    def forward(self, x, eps=None):
+        mu, logvar = self.encoder(x)
+        z = reparameterize(mu, logvar, eps=eps)
+        return self.decoder(z), mu, logvar
+
+    loss = staticmethod(F_hip.vae_loss)

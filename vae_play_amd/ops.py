@@ -1,0 +1,287 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/vaeplay_hip.h).
+
+Conventions: activations are 4-D tensors with *logical* NCHW shape stored channels_last
+(= NHWC in memory, what the kernels index), or 2-D [R, C] matrices; everything is fp32 on
+the current HIP device and stream.  These wrappers only marshal pointers -- all arithmetic
+happens in libvaeplay_hip.so.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU, "tanh": ACT_TANH,
+             "sigmoid": ACT_SIGMOID}
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.VaePlayHipError("vae_play_amd ops need tensors on the HIP device (no CPU path exists)")
+    if t.dtype != torch.float32:
+        raise _lib.VaePlayHipError(f"fp32 tensor expected, got {t.dtype}")
+    return c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(4, (nbytes + 3) // 4), dtype=torch.float32, device=like.device)
+
+
+def channels_last(x: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW tensor whose memory is NHWC: no copy when it already is, the HIP transpose
+    for a standard-contiguous NCHW tensor, torch's strided copy only for exotic strides."""
+    if x.is_contiguous(memory_format=torch.channels_last):
+        return x
+    if x.is_contiguous() and x.is_cuda and x.dtype == torch.float32:
+        return nchw_to_nhwc(x)
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def empty_cl(B: int, C: int, H: int, W: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty((B, C, H, W), dtype=torch.float32, device=like.device, memory_format=torch.channels_last)
+
+
+def _same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Same shape and same memory order (strides of size-1 dims are irrelevant)."""
+    if a.shape != b.shape:
+        return False
+    return all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
+def _is_nhwc(x: torch.Tensor) -> bool:
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+
+
+# ---- layout --------------------------------------------------------------------------------
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Copy a standard-contiguous NCHW tensor into a channels_last one with the HIP transpose."""
+    B, C, H, W = x.shape
+    x = x.contiguous()
+    out = empty_cl(B, C, H, W, x)
+    _lib.call("vp_nchw_to_nhwc_f32", _p(x), _p(out), B, C, H, W, _stream())
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    B, C, H, W = x.shape
+    assert _is_nhwc(x)
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    _lib.call("vp_nhwc_to_nchw_f32", _p(x), _p(out), B, C, H, W, _stream())
+    return out
+
+
+def pack_w5(w_ref: torch.Tensor, want_p0: bool, want_p1: bool) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """w_ref [Cs][Cb][5][5] -> p0 [Cs][25][Cb], p1 [Cb][25][Cs]."""
+    Cs, Cb = w_ref.shape[0], w_ref.shape[1]
+    assert w_ref.shape[2:] == (5, 5)
+    w_ref = w_ref.contiguous()
+    p0 = torch.empty((Cs, 25, Cb), dtype=torch.float32, device=w_ref.device) if want_p0 else None
+    p1 = torch.empty((Cb, 25, Cs), dtype=torch.float32, device=w_ref.device) if want_p1 else None
+    _lib.call("vp_pack_w5_f32", _p(w_ref), _p(p0), _p(p1), Cs, Cb, _stream())
+    return p0, p1
+
+
+# ---- 5x5 convolution families ----------------------------------------------------------------
+def conv5_gather(big: torch.Tensor, w_p0: torch.Tensor, bias: Optional[torch.Tensor], stride: int,
+                 act: int = ACT_NONE) -> torch.Tensor:
+    """small = act(bias + conv5x5_pad2_stride(big)); big is (B,Cb,Hb,Wb) channels_last."""
+    assert _is_nhwc(big)
+    B, Cb, Hb, Wb = big.shape
+    Cs = w_p0.shape[0]
+    assert w_p0.shape == (Cs, 25, Cb) and Hb % stride == 0 and Wb % stride == 0
+    Hs, Ws = Hb // stride, Wb // stride
+    out = empty_cl(B, Cs, Hs, Ws, big)
+    _lib.call("vp_conv5_gather_f32", _p(big), _p(w_p0), _p(bias), _p(out), B, Hs, Ws, Cb, Cs, stride, act, _stream())
+    return out
+
+
+def conv5_scatter(small: torch.Tensor, w_p1: torch.Tensor, stride: int) -> torch.Tensor:
+    """big = convT5x5_pad2_stride(small) (output_padding = stride-1); small is (B,Cs,Hs,Ws) channels_last."""
+    assert _is_nhwc(small)
+    B, Cs, Hs, Ws = small.shape
+    Cb = w_p1.shape[0]
+    assert w_p1.shape == (Cb, 25, Cs)
+    out = empty_cl(B, Cb, Hs * stride, Ws * stride, small)
+    _lib.call("vp_conv5_scatter_f32", _p(small), _p(w_p1), _p(out), B, Hs, Ws, Cs, Cb, stride, _stream())
+    return out
+
+
+def conv5_wgrad(big: torch.Tensor, small: torch.Tensor, stride: int) -> torch.Tensor:
+    """dW[Cs][Cb][5][5] in the reference layout."""
+    assert _is_nhwc(big) and _is_nhwc(small)
+    B, Cb, Hb, Wb = big.shape
+    _, Cs, Hs, Ws = small.shape
+    assert Hb == Hs * stride and Wb == Ws * stride and small.shape[0] == B
+    nbytes = _lib.load().vp_conv5_wgrad_workspace_bytes(B, Hs, Ws, Cb, Cs, stride)
+    ws = _ws(nbytes, big)
+    dw = torch.empty((Cs, Cb, 5, 5), dtype=torch.float32, device=big.device)
+    _lib.call("vp_conv5_wgrad_f32", _p(big), _p(small), _p(dw), B, Hs, Ws, Cb, Cs, stride, _p(ws), ws.numel() * 4, _stream())
+    return dw
+
+
+# ---- dense ------------------------------------------------------------------------------------
+def gemm(A: torch.Tensor, sam: int, sak: int, Bm: torch.Tensor, sbn: int, sbk: int, M: int, N: int, K: int, mode: int,
+         bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    nbytes = _lib.load().vp_gemm_workspace_bytes(M, N, K)
+    ws = _ws(nbytes, A) if nbytes else None
+    _lib.call("vp_gemm_f32", _p(A), sam, sak, _p(Bm), sbn, sbk, _p(out), out.stride(0), _p(bias), M, N, K, mode,
+              _p(ws), (ws.numel() * 4 if ws is not None else 0), _stream())
+    return out
+
+
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """y[M,N] = x[M,K] W[N,K]^T + bias."""
+    x, W = x.contiguous(), W.contiguous()
+    M, K = x.shape
+    N = W.shape[0]
+    return gemm(x, K, 1, W, K, 1, M, N, K, 0, bias)
+
+
+def linear_dgrad(dy: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """dx[M,K] = dy[M,N] W[N,K]."""
+    dy, W = dy.contiguous(), W.contiguous()
+    M, N = dy.shape
+    K = W.shape[1]
+    return gemm(dy, N, 1, W, 1, K, M, K, N, 1)
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW[N,K] = dy[M,N]^T x[M,K]."""
+    dy, x = dy.contiguous(), x.contiguous()
+    M, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, 1, N, x, 1, K, N, K, M, 2)
+
+
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    R, C = x2d.shape
+    assert x2d.is_contiguous()
+    ws = _ws(_lib.load().vp_colsum_workspace_bytes(R, C), x2d)
+    out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
+    _lib.call("vp_colsum_f32", _p(x2d), _p(out), R, C, _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+# ---- BatchNorm + activation over an [R][C] view ---------------------------------------------------
+def _rc(x: torch.Tensor) -> Tuple[int, int]:
+    if x.dim() == 2:
+        assert x.is_contiguous()
+        return x.shape[0], x.shape[1]
+    assert _is_nhwc(x)
+    B, C, H, W = x.shape
+    return B * H * W, C
+
+
+def bn_stats(x, eps, momentum, running_mean=None, running_var=None):
+    R, C = _rc(x)
+    mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    ws = _ws(_lib.load().vp_bn_workspace_bytes(R, C), x)
+    _lib.call("vp_bn_stats_f32", _p(x), R, C, float(eps), float(momentum), _p(mean), _p(rstd), _p(running_mean),
+              _p(running_var), _p(ws), ws.numel() * 4, _stream())
+    return mean, rstd
+
+
+def bn_act_fwd(x, mean, rstd, gamma, beta, act: int, slope: float = 0.0):
+    R, C = _rc(x)
+    y = torch.empty_like(x)  # preserves channels_last strides
+    _lib.call("vp_bn_act_fwd_f32", _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), R, C, act, float(slope), _stream())
+    return y
+
+
+def bn_act_bwd(x, dy, mean, rstd, gamma, beta, act: int, slope: float, batch_stats: bool, need_affine_grads: bool = True):
+    R, C = _rc(x)
+    assert _same_layout(dy, x)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if need_affine_grads else None
+    dbeta = torch.empty_like(dgamma) if need_affine_grads else None
+    ws = _ws(_lib.load().vp_bn_workspace_bytes(R, C), x)
+    _lib.call("vp_bn_act_bwd_f32", _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta),
+              R, C, act, float(slope), int(batch_stats), _p(ws), ws.numel() * 4, _stream())
+    return dx, dgamma, dbeta
+
+
+def act_fwd(x, act: int, slope: float = 0.0):
+    y = torch.empty_like(x)
+    _lib.call("vp_act_fwd_f32", _p(x), _p(y), x.numel(), act, float(slope), _stream())
+    return y
+
+
+def act_bwd_from_y(y, dy, act: int, slope: float = 0.0):
+    assert _same_layout(y, dy)
+    dx = torch.empty_like(y)
+    _lib.call("vp_act_bwd_from_y_f32", _p(y), _p(dy), _p(dx), y.numel(), act, float(slope), _stream())
+    return dx
+
+
+# ---- latent + loss ---------------------------------------------------------------------------------
+def latent_fwd(mu, logvar, eps, want_kl: bool = True):
+    B, Z = mu.shape
+    mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+    z = torch.empty_like(mu)
+    kl = torch.empty((B,), dtype=torch.float32, device=mu.device) if want_kl else None
+    _lib.call("vp_latent_fwd_f32", _p(mu), _p(logvar), _p(eps), _p(z), _p(kl), B, Z, _stream())
+    return z, kl
+
+
+def latent_bwd(mu, logvar, eps, dz, gkl, gkl_scalar: float = 0.0):
+    B, Z = mu.shape
+    dmu = torch.empty_like(mu)
+    dlv = torch.empty_like(mu)
+    _lib.call("vp_latent_bwd_f32", _p(mu.contiguous()), _p(logvar.contiguous()), _p(eps.contiguous()),
+              _p(dz.contiguous() if dz is not None else None), _p(gkl.contiguous() if gkl is not None else None),
+              float(gkl_scalar), _p(dmu), _p(dlv), B, Z, _stream())
+    return dmu, dlv
+
+
+def bce_sum(p, t):
+    assert _same_layout(p, t)
+    n = p.numel()
+    ws = _ws(_lib.load().vp_reduce_workspace_bytes(n), p)
+    out = torch.empty((1,), dtype=torch.float32, device=p.device)
+    _lib.call("vp_bce_sum_f32", _p(p), _p(t), n, _p(out), _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+def bce_bwd(p, t, g: Optional[torch.Tensor], gscale: float = 1.0):
+    assert _same_layout(p, t)
+    dp = torch.empty_like(p)
+    _lib.call("vp_bce_bwd_f32", _p(p), _p(t), _p(g), float(gscale), _p(dp), p.numel(), _stream())
+    return dp
+
+
+def bce_sigmoid_bwd(p, t, gscale: float):
+    assert _same_layout(p, t)
+    dl = torch.empty_like(p)
+    _lib.call("vp_bce_sigmoid_bwd_f32", _p(p), _p(t), float(gscale), _p(dl), p.numel(), _stream())
+    return dl
+
+
+def tensor_sum(x):
+    n = x.numel()
+    ws = _ws(_lib.load().vp_reduce_workspace_bytes(n), x)
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _lib.call("vp_sum_f32", _p(x), n, _p(out), _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+# ---- optimiser -----------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step: int, grad_scale: float = 1.0):
+    _lib.call("vp_adam_f32", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+              int(step), float(grad_scale), _stream())
+
+
+def rmsprop_step(p, g, sq, lr, alpha, eps, grad_scale: float = 1.0):
+    _lib.call("vp_rmsprop_f32", _p(p), _p(g), _p(sq), p.numel(), float(lr), float(alpha), float(eps), float(grad_scale), _stream())

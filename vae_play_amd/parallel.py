@@ -1,0 +1,75 @@
+"""Data parallelism for the VAE step: one process per GPU, the minibatch sharded by rank,
+replicated weights, and ONE sum all-reduce of the flat gradient arena per step
+(torch.distributed backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no distributed code at all; this is new functionality
+defined by BASELINE.json's north_star.  BatchNorm statistics stay per-rank: the
+parity definition for W ranks is "the average of W single-shard reference gradients".
+The 1/W factor is folded into the fused optimiser kernel (grad_scale), not a separate pass.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(global_batch: int, rank: int, world: int) -> tuple:
+    """Rank r owns x[r*B/W : (r+1)*B/W]."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_flat_grads(flat_grad: torch.Tensor, group=None, async_op: bool = False):
+    """The step's single collective: SUM all-reduce of the gradient arena."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return None
+
+
+def broadcast_flat_params(flat_param: torch.Tensor, src: int = 0, group=None) -> None:
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_param, src=src, group=group)
+
+
+class DataParallelStep:
+    """Wraps a flat-arena optimiser: ``dp.step()`` = all-reduce(sum) + fused update with 1/W.
+
+    Usage mirrors the reference loop body (train_BE.py:62-64):
+        optim.zero_grad(); loss.backward(); dp.step()
+    """
+
+    def __init__(self, optimizer, group=None, broadcast_from: Optional[int] = 0):
+        self.optimizer, self.group = optimizer, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        optimizer.grad_scale = 1.0 / self.world
+        if broadcast_from is not None:
+            broadcast_flat_params(optimizer.flat_param, broadcast_from, group)
+
+    def zero_grad(self) -> None:
+        self.optimizer.zero_grad()
+
+    def step(self) -> None:
+        allreduce_flat_grads(self.optimizer.flat_grad, self.group)
+        self.optimizer.step()
