@@ -46,13 +46,19 @@ def parse():
                     "(roofline events are then taken in a separate instrumented pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--tags-out", type=str, default="", help="write per-layer conv timings (JSON) to this file")
     return ap.parse_args()
 
 
 def cpu_baseline(args):
     """The oracle (= reference algorithm on torch CPU) on the host cores: bounded sample."""
     from oracle import ref_cpu as O
-    cores = os.cpu_count() or 1
+    # threads = the CPU share this process may actually use (affinity), capped by VAEPLAY_CPU_THREADS
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("VAEPLAY_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
     B, C, S, z = args.batch_per_gpu, args.channels, args.img, args.z
     L = O.iter_level_for(S)
@@ -138,6 +144,14 @@ def main():
             d[0] += flops
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
+        if args.tags_out:
+            per = {}
+            for name, tag, flops, e0, e1 in timers["events"]:
+                d = per.setdefault(tag, [0.0, 0.0, 0])
+                d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+            with open(args.tags_out, "w") as f:
+                json.dump({k: {"ms": round(v[1] / v[2] * 1e3, 4), "gflop": round(v[0] / v[2] / 1e9, 3),
+                               "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in per.items()}, f, indent=1)
         dom = max(fam, key=lambda k: fam[k][1])
         tot_f = sum(v[0] for v in fam.values())
         tot_t = sum(v[1] for v in fam.values())

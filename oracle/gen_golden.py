@@ -52,7 +52,8 @@ def bit_equal(a: torch.Tensor, b: torch.Tensor, what: str):
 
 
 def np_(t):
-    return t.detach().cpu().numpy()
+    # copy: parameters / BN buffers are updated in place by later steps
+    return t.detach().cpu().numpy().copy()
 
 
 # --------------------------------------------------------------------------
@@ -249,8 +250,10 @@ def main():
     # whole composed step; 32x32x1 is BASELINE config 1 run at the nearest valid size
     save("step_32x32x1_z16_b4_adam", step_fixture(nets, "s32", 1, 32, 16, 4, "adam", 3, True))
     save("step_32x32x1_z16_b4_rmsprop", step_fixture(nets, "s32r", 1, 32, 16, 4, "rmsprop", 1, False))
-    save("step_64x64x3_z64_b2_adam", step_fixture(nets, "s64", 3, 64, 64, 2, "adam", 1, False))
-    save("step_128x128x3_z128_b2_adam", step_fixture(nets, "s128", 3, 128, 128, 2, "adam", 1, False))
+    save("step_64x64x3_z64_b4_adam", step_fixture(nets, "s64", 3, 64, 64, 4, "adam", 1, False))
+    save("step_128x128x3_z128_b4_adam", step_fixture(nets, "s128", 3, 128, 128, 4, "adam", 1, False))
+    # BASELINE config 3 at its per-GPU shard size (32 images): the shape bench.py times
+    save("step_128x128x3_z128_b32_adam", step_fixture(nets, "s128b32", 3, 128, 128, 32, "adam", 1, False))
     print("oracle == reference (bit-exact) on every fixture")
 
 

@@ -25,3 +25,17 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the measured relative errors of the GPU parity run (evidence for DESIGN.md / profiles)."""
+    try:
+        from tests import util
+        if util.ERRORS:
+            import json
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "parity_errors.json"), "w") as f:
+                json.dump(dict(sorted(util.ERRORS.items())), f, indent=1)
+    except Exception:
+        pass

@@ -21,8 +21,13 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
+ERRORS = {}   # what -> worst relative error seen this session (dumped by conftest at session end)
+
+
 def assert_close(a, b, tol, what=""):
     e = rel_err(a, b)
+    key = f"{os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]}::{what}"
+    ERRORS[key] = max(ERRORS.get(key, 0.0), e)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
     return e
 
@@ -33,3 +38,10 @@ def load_golden(name):
 
 def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def record(what: str, err: float) -> float:
+    """Log a relative error for the session report without asserting."""
+    key = f"{os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]}::{what}"
+    ERRORS[key] = max(ERRORS.get(key, 0.0), float(err))
+    return err

@@ -1,6 +1,7 @@
 // 5x5 convolution families on the MFMA implicit-GEMM kernel (igemm.h) + weight packing + wgrad reduce.
 #include "common.h"
 #include "igemm.h"
+#include "narrow.h"
 
 namespace vp {
 
@@ -15,20 +16,6 @@ __global__ void pack_w5_kernel(const float* __restrict__ w, float* __restrict__ 
     const float v = w[i];
     if (p0) p0[((size_t)cs * kTaps + t) * Cb + cb] = v;
     if (p1) p1[((size_t)cb * kTaps + t) * Cs + cs] = v;
-  }
-}
-
-// dw_ref[cs][cb][tap] = sum_split slab[split][tap][cs][cb]; thread per (tap, cs, cb): coalesced
-// slab reads, stride-25 writes (small tensor).
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cs, int Cb, int nsplit) {
-  const size_t per = (size_t)kTaps * Cs * Cb;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
-    const int cb = (int)(i % Cb);
-    const size_t r = i / Cb;
-    const int cs = (int)(r % Cs), t = (int)(r / Cs);
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += slab[(size_t)sp * per + i];
-    dw[((size_t)cs * Cb + cb) * kTaps + t] = s;
   }
 }
 
@@ -53,6 +40,7 @@ int vp_conv5_gather_f32(const float* big, const float* w_p0, const float* bias, 
   VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv5_gather_f32: epilogue supports none|sigmoid");
   VP_REQUIRE((long)B * Hs * Ws * stride * stride < (1L << 30), "vp_conv5_gather_f32: pixel count overflows int");
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  if (narrow_gather_applicable(g, act)) return narrow_gather_launch(big, w_p0, bias, small_out, g, act, (hipStream_t)stream);
   ProbF p = make_probF(big, w_p0, bias, small_out, g, act);
   launch_igemm(p, p.M, p.N, 1, (hipStream_t)stream);
   return check_launch("vp_conv5_gather_f32");
@@ -72,6 +60,7 @@ int vp_conv5_scatter_f32(const float* small, const float* w_p1, float* big_out, 
 
 size_t vp_conv5_wgrad_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  if (narrow_wgrad_kind(g)) return narrow_wgrad_ws_floats(g) * sizeof(float);
   return wgrad_slab_floats(g, wgrad_nsplit(g)) * sizeof(float);
 }
 
@@ -81,6 +70,10 @@ int vp_conv5_wgrad_f32(const float* big, const float* small, float* dw_ref, int 
   VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0, "vp_conv5_wgrad_f32: bad shape");
   VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_wgrad_f32: stride must be 1 or 2");
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  if (narrow_wgrad_kind(g)) {
+    if (ws_bytes < narrow_wgrad_ws_floats(g) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_wgrad_f32: workspace too small");
+    return narrow_wgrad_launch(big, small, dw_ref, g, (float*)ws, (hipStream_t)stream);
+  }
   const int ns = wgrad_nsplit(g);
   if (ws_bytes < wgrad_slab_floats(g, ns) * sizeof(float))
     return fail(VP_ERR_WORKSPACE, "vp_conv5_wgrad_f32: workspace %zu < %zu", ws_bytes, wgrad_slab_floats(g, ns) * sizeof(float));
@@ -88,9 +81,6 @@ int vp_conv5_wgrad_f32(const float* big, const float* small, float* dw_ref, int 
   launch_igemm(p, p.M, p.N, kTaps * ns, (hipStream_t)stream);
   int rc = check_launch("vp_conv5_wgrad_f32(main)");
   if (rc) return rc;
-  const size_t per = (size_t)kTaps * Csmall * Cbig;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(per, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dw_ref,
-                     Csmall, Cbig, ns);
-  return check_launch("vp_conv5_wgrad_f32(reduce)");
+  return slab_reduce_launch((const float*)ws, dw_ref, Csmall, Cbig, ns, (hipStream_t)stream);
 }
 }
