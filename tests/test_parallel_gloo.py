@@ -1,0 +1,156 @@
+"""Data-parallel path with torch.distributed, world_size 2.
+
+CPU (gloo) test: exercises vae_play_amd.parallel + the flat gradient arena exactly as the GPU
+step uses them (shard the batch by rank, ONE sum all-reduce of the arena, 1/W folded into the
+update) with the CPU oracle standing in as the per-rank gradient producer, and checks the result
+against the multi-GPU parity definition of SURVEY.md 8e: "the average of W single-shard reference
+gradients" (BatchNorm statistics stay per rank).
+
+GPU test (-m gpu): two ranks share the one GPU of the box (gloo backend on device tensors; RCCL
+needs one GPU per rank) and run the real fused HIP step + DataParallelStep; the updated weights
+must equal the oracle's data-parallel definition.
+"""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+C, S, Z, L, GLOBAL_B, WORLD = 1, 32, 16, 2, 8, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_reference():
+    """Single-process statement of the DP step: average of per-shard oracle gradients, one Adam step."""
+    from oracle import ref_cpu as O
+    x, eps = O.synthetic_batch(GLOBAL_B, C, S, Z)
+    p0 = O.init_params(C, Z, L, seed=0)
+    names = O.trainable_names(p0)
+    grads = {n: torch.zeros_like(p0[n]) for n in names}
+    per = GLOBAL_B // WORLD
+    for r in range(WORLD):
+        p = O.clone_params(p0)
+        O.require_grad(p)
+        O.train_step(p, None, x[r * per:(r + 1) * per], eps[r * per:(r + 1) * per], L)
+        for n in names:
+            grads[n] += p[n].grad / WORLD
+    p = O.clone_params(p0)
+    O.require_grad(p)
+    opt = O.make_optimizer(p, "adam", 1e-4)
+    for n in names:
+        p[n].grad = grads[n].clone()
+    opt.step()
+    return x, eps, p0, grads, {n: p[n].detach() for n in names}
+
+
+def _worker_cpu(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import ref_cpu as O
+    from vae_play_amd import optim, parallel
+    r, w, _ = parallel.init_from_env("gloo")
+    assert (r, w) == (rank, WORLD)
+    x, eps = O.synthetic_batch(GLOBAL_B, C, S, Z)
+    lo, hi = parallel.shard_bounds(GLOBAL_B, rank, WORLD)
+    p0 = O.init_params(C, Z, L, seed=0)
+    if rank != 0:  # replicas start different on purpose: the broadcast must fix that
+        for n in O.trainable_names(p0):
+            p0[n] = p0[n] + 1.0
+    params = {n: torch.nn.Parameter(p0[n].clone()) for n in O.trainable_names(p0)}
+    arena = optim.FlatArena(params.values())
+    parallel.broadcast_flat_params(arena.flat_param, 0)
+    p = dict(p0)
+    p.update(params)
+    arena.zero_grad()
+
+    def hook(_):
+        parallel.allreduce_flat_grads(arena.flat_grad)       # the step's single collective
+
+    # forward/backward of this rank's shard; autograd accumulates into the arena views
+    out = O.vae_forward(p, x[lo:hi], eps[lo:hi], L, training=True)
+    out["loss"].backward()
+    for n, q in params.items():
+        assert q.grad.data_ptr() == arena.flat_grad.data_ptr() + 4 * arena.offsets[list(params).index(n)], "grad left the arena"
+    hook(None)
+    scale = 1.0 / dist.get_world_size()
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4)
+    arena.flat_grad.mul_(scale)                               # the HIP optimiser folds this into its kernel
+    opt.step()
+    torch.save({"grads": {n: q.grad.clone() for n, q in params.items()}, "params": {n: q.detach().clone() for n, q in params.items()}},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_gloo_cpu_matches_average_of_shard_gradients():
+    x, eps, p0, grads, new_params = _dp_reference()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_cpu, args=(_free_port(), d), nprocs=WORLD, join=True)
+        res = [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=True) for r in range(WORLD)]
+    for n in grads:
+        for r in range(WORLD):
+            # same arithmetic on a different thread count -> different fp32 summation order
+            err = (res[r]["grads"][n] - grads[n]).abs().max().item() / (grads[n].abs().max().item() + 1e-12)
+            assert err < 1e-4, f"rank {r} grad {n}: rel err {err}"
+            # one Adam step of size lr; near-zero gradient elements may round to either sign
+            d_ = (res[r]["params"][n] - new_params[n]).abs()
+            assert (d_ > 1e-5).double().mean().item() < 1e-3, f"rank {r} param {n}"
+        assert torch.equal(res[0]["params"][n], res[1]["params"][n]), f"replicas diverged: {n}"
+
+
+def test_shard_bounds():
+    from vae_play_amd import parallel
+    assert parallel.shard_bounds(256, 3, 8) == (96, 128)
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(10, 0, 4)
+
+
+def _worker_gpu(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK="0")
+    import vae_play_amd as V
+    from oracle import ref_cpu as O
+    from vae_play_amd import engine, optim, parallel
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    x, eps = O.synthetic_batch(GLOBAL_B, C, S, Z)
+    lo, hi = parallel.shard_bounds(GLOBAL_B, rank, WORLD)
+    vae = V.VAE(S, Z, C, init_rule=False)
+    vae.load_state_dict(O.init_params(C, Z, L, seed=0))
+    vae.to("cuda").train()
+    opt = optim.Adam(vae.parameters(), lr=1e-4)
+    fused = engine.FusedVAEStep(vae, opt, hi - lo, S, C)
+    assert abs(opt.grad_scale - 1.0 / WORLD) < 1e-12
+    fused.forward_backward(x[lo:hi].cuda(), eps[lo:hi].cuda())
+    parallel.allreduce_flat_grads(opt.flat_grad)
+    grads = {n: q.grad.detach().cpu() / WORLD for n, q in vae.named_parameters()}
+    opt.step()
+    torch.cuda.synchronize()
+    torch.save({"grads": grads, "params": {n: q.detach().cpu() for n, q in vae.named_parameters()}}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_dp_two_ranks_on_one_gpu_matches_oracle_definition():
+    x, eps, p0, grads, new_params = _dp_reference()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_gpu, args=(_free_port(), d), nprocs=WORLD, join=True)
+        res = [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=True) for r in range(WORLD)]
+    for n in grads:
+        scale = grads[n].abs().max().item() + 1e-12
+        for r in range(WORLD):
+            err = (res[r]["grads"][n] - grads[n]).abs().max().item() / scale
+            assert err < 1e-3, f"rank {r} averaged grad {n}: rel err {err}"
+            d_ = (res[r]["params"][n] - new_params[n]).abs()
+            assert (d_ > 1e-5).double().mean().item() < 1e-3, f"rank {r} param {n}"
+        assert torch.equal(res[0]["params"][n], res[1]["params"][n]), f"replicas diverged: {n}"
