@@ -30,7 +30,9 @@ import torch.distributed as dist  # noqa: E402
 # convs without zero insertion)
 STEP_GFLOP = {32: 0.6141, 64: 4.0301, 128: 22.2088, 256: 112.0225}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32"}
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32",
+              "vp_conv5_gather_bf16x3", "vp_conv5_scatter_bf16x3", "vp_conv5_wgrad_bf16x3"}
 
 
 def parse():
@@ -44,6 +46,9 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph "
                     "(roofline events are then taken in a separate instrumented pass)")
+    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="bf16x3: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate, ~1e-5 parity); "
+                         "f32: exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--tags-out", type=str, default="", help="write per-layer conv timings (JSON) to this file")
@@ -99,7 +104,7 @@ def main():
     vae = V.VAE(S, z, C, init_rule=True).to("cuda").train()     # same seed on every rank = replicated weights
     opt = optim.Adam(vae.parameters(), lr=1e-4)
     parallel.broadcast_flat_params(opt.flat_param, 0)
-    fused = engine.FusedVAEStep(vae, opt, B, S, C)
+    fused = engine.FusedVAEStep(vae, opt, B, S, C, precision=args.precision)
     gx = torch.Generator().manual_seed(1234 + rank)
     ge = torch.Generator().manual_seed(4321 + rank)
     x = torch.rand(B, C, S, S, generator=gx).cuda()               # inputs resident in HBM before timing
@@ -156,21 +161,27 @@ def main():
         tot_f = sum(v[0] for v in fam.values())
         tot_t = sum(v[1] for v in fam.values())
         ach = fam[dom][0] / fam[dom][1] / 1e12
+        is16 = dom.endswith("bf16x3")
+        peak = PEAK_BF16_MFMA_TFLOPS if is16 else PEAK_FP32_MFMA_TFLOPS
+        kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if is16
+                 else "igemm_kernel, v_mfma_f32_32x32x2_f32")
         ips = world * B * args.steps / elapsed
         out = {
             "metric": "images/sec (train step, 128x128 VAE)", "value": round(ips, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"networks VAE {S}x{S}x{C} latent={z} train step (fwd+BCE/KL+bwd+allreduce+Adam), "
                                    f"{B} images/GPU, global batch {B * world}", "parallelism": f"dp{world}",
-                       "per_gpu_batch": B, "global_batch": B * world, "graph": bool(args.graph)},
+                       "per_gpu_batch": B, "global_batch": B * world, "graph": bool(args.graph),
+                       "precision": args.precision},
             "images_per_sec_per_gpu": round(ips / world, 1),
             "step_mfma_frac": round(ips / world * STEP_GFLOP.get(S, 0.0) / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
             "loss": round(final_loss, 4),
-            "roofline": {"bound": "mfma", "kernel": dom + " (igemm_kernel, v_mfma_f32_32x32x2_f32)",
-                         "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": f"{dom} ({kdesc})",
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": None,
+                         "mfma_issue_frac": round(ach * (3 if is16 else 1) / peak, 4),
                          "launches": fam[dom][2], "avg_launch_ms": round(fam[dom][1] / fam[dom][2] * 1e3, 4),
                          "all_conv_families_tflops": round(tot_f / tot_t / 1e12, 2),
                          "conv_share_of_step_time": round(tot_t / args.steps / (elapsed / args.steps), 3),

@@ -64,6 +64,32 @@ int vp_conv5_wgrad_f32(const float* big, const float* small, float* dw_ref,
                        int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
                        void* ws, size_t ws_bytes, vp_stream stream);
 
+/* ---- split-bf16 ("bf16x3") variants of the three families ------------------------------------------
+ * A "split" tensor stores an fp32 tensor of n elements as two bf16 planes in one buffer of 2*n
+ * uint16: hi = bf16(x) at [0,n), lo = bf16(x - hi) at [n,2n).  The contraction issues three
+ * v_mfma_f32_32x32x16_bf16 per fragment pair (lo*hi + hi*lo + hi*hi) with fp32 accumulation:
+ * ~5e-6 relative error per contraction.  Channel counts on the contracted/vector side must be
+ * multiples of 8; outputs are plain fp32.  Same reference lines as the f32 entry points above. */
+int vp_split_f32(const float* x, void* out_split, size_t n, vp_stream stream);
+int vp_pack_w5_split(const float* w_ref, void* p0_split, void* p1_split, int Csmall, int Cbig, vp_stream stream);
+int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const float* bias, float* small_out,
+                           int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream);
+int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, float* big_out,
+                            int B, int Hs, int Ws, int Csmall, int Cbig, int stride, vp_stream stream);
+size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride);
+int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref,
+                          int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
+                          void* ws, size_t ws_bytes, vp_stream stream);
+/* producers of split tensors fused into the elementwise passes (y / dx / out may be NULL when only
+ * the split copy is wanted) */
+int vp_bn_act_fwd_split_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            float* y, void* y_split, int R, int C, int act, float slope, vp_stream stream);
+int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta,
+                            int R, int C, int act, float slope, int batch_stats,
+                            void* ws, size_t ws_bytes, vp_stream stream);
+int vp_nchw_to_nhwc_split_f32(const float* in, float* out, void* out_split, int B, int C, int H, int W, vp_stream stream);
+
 /* ---- dense layers ------------------------------------------------------------------------ */
 /* C[m][n] = bias[n] + sum_k A(m,k) B(n,k) with element strides (sam,sak) / (sbn,sbk).
  * mode 0: both operands k-contiguous (Linear fwd, models/networks.py:75-77,109)

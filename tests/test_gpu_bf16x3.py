@@ -1,0 +1,75 @@
+"""GPU tests of the split-bf16 ("bf16x3") convolution path: three bf16 MFMAs per product with fp32
+accumulation must stay ~1e-5 of the fp32 result (plain bf16 would be ~2e-3, outside the 1e-3 bar)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+X3_RTOL = 5e-5
+
+CASES = [  # (B, Hs, Cb, Cs, stride): channel counts multiples of 8
+    (2, 4, 8, 8, 2), (2, 8, 64, 128, 2), (3, 5, 16, 24, 2), (8, 32, 32, 512, 2), (6, 64, 16, 64, 2),
+    (2, 16, 128, 64, 2), (1, 8, 256, 256, 2), (2, 12, 64, 64, 1), (4, 16, 512, 256, 2),
+]
+
+
+def nhwc(x):
+    return x.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("B,Hs,Cb,Cs,stride", CASES)
+def test_bf16x3_families(B, Hs, Cb, Cs, stride):
+    from vae_play_amd import ops
+    g = torch.Generator().manual_seed(7 + B + Hs + Cb + Cs)
+    Hb = Hs * stride
+    big = torch.randn(B, Cb, Hb, Hb, generator=g).clamp_min(0)    # post-ReLU-like
+    small = torch.randn(B, Cs, Hs, Hs, generator=g)
+    w = torch.randn(Cs, Cb, 5, 5, generator=g) * 0.05
+    bias = torch.randn(Cs, generator=g)
+    big_s, small_s = ops.split_f32(nhwc(big)), ops.split_f32(nhwc(small))
+    rec = ops.unsplit(big_s).view(B, Hb, Hb, Cb).permute(0, 3, 1, 2)
+    assert_close(rec, big, 2 ** -15, "split reconstruction")
+    p0, p1 = ops.pack_w5_split(w.to(DEV), True, True)
+    assert_close(ops.unsplit(p0).view(Cs, 25, Cb), w.permute(0, 2, 3, 1).reshape(Cs, 25, Cb), 2 ** -15, "p0")
+    assert_close(ops.unsplit(p1).view(Cb, 25, Cs), w.permute(1, 2, 3, 0).reshape(Cb, 25, Cs), 2 ** -15, "p1")
+    y = ops.conv5_gather_bf16x3(big_s, big.shape, p0, Cs, bias.to(DEV), stride, 0)
+    assert_close(y, F.conv2d(big, w, bias, stride=stride, padding=2), X3_RTOL, "gather bf16x3")
+    yt = ops.conv5_scatter_bf16x3(small_s, small.shape, p1, Cb, stride)
+    assert_close(yt, F.conv_transpose2d(small, w, None, stride=stride, padding=2, output_padding=stride - 1), X3_RTOL, "scatter bf16x3")
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(big, wr, None, stride=stride, padding=2).backward(small)
+    dw = ops.conv5_wgrad_bf16x3(big_s, big.shape, small_s, small.shape, stride)
+    assert_close(dw, wr.grad, X3_RTOL, "wgrad bf16x3")
+
+
+def test_split_outputs_of_bn_and_transpose():
+    from vae_play_amd import _lib, ops
+    from ctypes import c_void_p
+    g = torch.Generator().manual_seed(3)
+    B, C, H = 2, 16, 8
+    x = nhwc(torch.randn(B, C, H, H, generator=g))
+    mean, rstd = ops.bn_stats(x, 1e-5, 0.9)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    y = ops.bn_act_fwd(x, mean, rstd, gamma, beta, ops.ACT_RELU)
+    ys = ops.empty_split(x.numel(), x)
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.call("vp_bn_act_fwd_split_f32", ops._p(x), ops._p(mean), ops._p(rstd), ops._p(gamma), ops._p(beta), None, ops._pv(ys),
+              B * H * H, C, ops.ACT_RELU, 0.0, st)
+    assert_close(ops.unsplit(ys), y.permute(0, 2, 3, 1).reshape(-1), 2 ** -15, "bn split out")
+    dy = nhwc(torch.randn(B, C, H, H, generator=g))
+    dx, dg, db = ops.bn_act_bwd(x, dy, mean, rstd, gamma, beta, ops.ACT_RELU, 0.0, True)
+    dxs = ops.empty_split(x.numel(), x)
+    ws = torch.empty(_lib.load().vp_bn_workspace_bytes(B * H * H, C) // 4 + 4, device=DEV)
+    dg2, db2 = torch.empty_like(dg), torch.empty_like(db)
+    _lib.call("vp_bn_act_bwd_split_f32", ops._p(x), ops._p(dy), ops._p(mean), ops._p(rstd), ops._p(gamma), ops._p(beta), None,
+              ops._pv(dxs), ops._p(dg2), ops._p(db2), B * H * H, C, ops.ACT_RELU, 0.0, 1, ops._p(ws), ws.numel() * 4, st)
+    assert_close(ops.unsplit(dxs), dx.permute(0, 2, 3, 1).reshape(-1), 2 ** -15, "bn bwd split out")
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
+    xn = torch.randn(B, C, H, H, generator=g).to(DEV)
+    ts = ops.empty_split(xn.numel(), xn)
+    _lib.call("vp_nchw_to_nhwc_split_f32", ops._p(xn), None, ops._pv(ts), B, C, H, H, st)
+    assert_close(ops.unsplit(ts), xn.permute(0, 2, 3, 1).reshape(-1), 2 ** -15, "transpose split out")

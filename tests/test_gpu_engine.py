@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def build(C, S, z, B, kind="adam"):
+def build(C, S, z, B, kind="adam", precision="f32"):
     import vae_play_amd as V
     from vae_play_amd import engine, optim
     from oracle import ref_cpu as O
@@ -20,18 +20,19 @@ def build(C, S, z, B, kind="adam"):
     vae.load_state_dict(p0)
     vae.to(DEV).train()
     opt = (optim.Adam if kind == "adam" else optim.RMSprop)(vae.parameters(), lr=1e-4)
-    step = engine.FusedVAEStep(vae, opt, B, S, C)
+    step = engine.FusedVAEStep(vae, opt, B, S, C, precision=precision)
     return vae, opt, step, p0, L
 
 
 @pytest.mark.parametrize("name", ["step_32x32x1_z16_b4_adam", "step_64x64x3_z64_b4_adam", "step_128x128x3_z128_b4_adam",
                                   "step_128x128x3_z128_b32_adam"])
-def test_fused_step_against_reference_golden(name):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_fused_step_against_reference_golden(name, precision):
     from oracle import ref_cpu as O
     g = load_golden(name)
     C, S, z, B = (int(g[k]) for k in ("meta_C", "meta_S", "meta_z", "meta_B"))
     steps = int(g["meta_steps"])
-    vae, opt, fused, p0, L = build(C, S, z, B)
+    vae, opt, fused, p0, L = build(C, S, z, B, precision=precision)
     x, eps = O.synthetic_batch(B, C, S, z)
     xd, epsd = x.to(DEV), eps.to(DEV)
     names = [n for n, _ in vae.named_parameters()]
@@ -50,10 +51,16 @@ def test_fused_step_against_reference_golden(name):
             for n in names:
                 gr = params[n].grad.detach().cpu().contiguous()
                 l2 = g[f"grad_l2/{n}"][0]
-                record(f"grad_l2_rel/{n}", abs(gr.double().pow(2).sum().sqrt().item() - l2) / (l2 + 1e-30))
+                gerr = record(f"grad_l2_rel/{n}", abs(gr.double().pow(2).sum().sqrt().item() - l2) / (l2 + 1e-30))
+                # BASELINE's 1e-3 bar is on the outputs (x_tilde, mu/logvar, loss; asserted above for both
+                # precisions).  Gradients are held to 1e-3 in exact-fp32 mode; in bf16x3 mode the ~5e-6
+                # contraction noise is amplified along the backward chain by small-batch BatchNorm,
+                # so each gradient tensor's norm is held to 5e-3 (measured worst: 2.6e-3 at batch 4).
+                budget = tol if precision == "f32" else 5e-3
+                assert gerr <= budget, f"grad l2 {n}: {gerr:.2e} > {budget:.0e}"
                 idx = O.sample_indices(gr.numel())
                 d = (gr.flatten()[idx].double() - t(g[f"grad_samples/{n}"])).abs().max().item()
-                assert d <= tol * 30 * max(l2 / gr.numel() ** 0.5, 1e-12), f"grad samples {n}"
+                assert d <= (tol if precision == "f32" else 5e-3) * 30 * max(l2 / gr.numel() ** 0.5, 1e-12), f"grad samples {n}"
             sd = vae.state_dict()
             for k in g:
                 if k.startswith("bn/"):
@@ -64,7 +71,8 @@ def test_fused_step_against_reference_golden(name):
             l2 = g[f"param{step}_l2/{n}"][0]
             pv = params[n].detach().cpu().double()
             upd = 1e-4 * step * pv.numel() ** 0.5
-            assert abs(pv.pow(2).sum().sqrt().item() - l2) <= 1e-5 * l2 + 0.02 * upd, f"param l2 step {step} {n}"
+            slack = 0.02 if precision == "f32" else 0.06
+            assert abs(pv.pow(2).sum().sqrt().item() - l2) <= 1e-5 * l2 + slack * upd, f"param l2 step {step} {n}"
     fused.sync_counters()
     assert int(vae.encoder.conv[0].bn.num_batches_tracked) == steps
 
@@ -73,7 +81,7 @@ def test_fused_step_equals_autograd_modules_and_graph_replay():
     import vae_play_amd as V
     from oracle import ref_cpu as O
     C, S, z, B = 3, 32, 16, 8
-    vae, opt, fused, p0, L = build(C, S, z, B)
+    vae, opt, fused, p0, L = build(C, S, z, B, precision="f32")
     x, eps = O.synthetic_batch(B, C, S, z)
     xd, epsd = x.to(DEV), eps.to(DEV)
     sd0 = {k: v.clone() for k, v in vae.state_dict().items()}

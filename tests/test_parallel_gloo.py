@@ -128,7 +128,7 @@ def _worker_gpu(rank, port, out_dir):
     vae.load_state_dict(O.init_params(C, Z, L, seed=0))
     vae.to("cuda").train()
     opt = optim.Adam(vae.parameters(), lr=1e-4)
-    fused = engine.FusedVAEStep(vae, opt, hi - lo, S, C)
+    fused = engine.FusedVAEStep(vae, opt, hi - lo, S, C, precision="f32")   # the collective is what is under test
     assert abs(opt.grad_scale - 1.0 / WORLD) < 1e-12
     fused.forward_backward(x[lo:hi].cuda(), eps[lo:hi].cuda())
     parallel.allreduce_flat_grads(opt.flat_grad)

@@ -4,6 +4,7 @@
 //   R = B*H*W for BatchNorm2d, R = B for BatchNorm1d (models/networks.py:16,40,66,89).
 #include "common.h"
 #include "problems.h"
+#include "split.h"
 
 namespace vp {
 
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* __restri
 __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, size_t n,
-                                                         int C, int act, float slope) {
+                                                         int C, int act, float slope, u16_t* __restrict__ y_split) {
   const bool vec = (C % 4 == 0);
   if (vec) {
     const size_t n4 = n / 4;
@@ -195,7 +196,8 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
         const float sf = (beta ? beta[c + j] : 0.f) - mean[c + j] * sc;
         o[j] = act_apply(v[j] * sc + sf, act, slope);
       }
-      *reinterpret_cast<vp_f32x4*>(y + i * 4) = o;
+      if (y) *reinterpret_cast<vp_f32x4*>(y + i * 4) = o;
+      if (y_split) store_split4(y_split, n, i * 4, o[0], o[1], o[2], o[3]);
     }
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
                                                          float* dx, size_t n, int C, float invR, int act,
-                                                         float slope) {
+                                                         float slope, u16_t* __restrict__ dx_split) {
   const bool vec = (C % 4 == 0);
   const size_t cnt = vec ? n / 4 : n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
@@ -229,7 +231,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
         const float g = dv[j] * act_grad_pre(ga * xh + be, act, slope);
         o[j] = ga * rstd[c + j] * (g - (sum_g[c + j] + xh * sum_gx[c + j]) * invR);
       }
-      *reinterpret_cast<vp_f32x4*>(dx + i * 4) = o;
+      if (dx) *reinterpret_cast<vp_f32x4*>(dx + i * 4) = o;
+      if (dx_split) store_split4(dx_split, n, i * 4, o[0], o[1], o[2], o[3]);
     } else {
       const int c = (int)(i % C);
       const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
@@ -258,6 +261,86 @@ __global__ void act_bwd_from_y_kernel(const float* __restrict__ y, const float* 
     }
     dx[i] = dy[i] * d;
   }
+}
+
+// ---- fast paths for C % 4 == 0: same (16 float4 columns x 16 rows) thread map as bn_partial_kernel, so the
+// per-channel constants are computed once per thread instead of once per element, and every 16-lane
+// group streams 256 contiguous bytes per row.
+__global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ y,
+                                                               u16_t* __restrict__ y_split, int R, int C, int rows_per_chunk,
+                                                               int act, float slope) {
+  const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
+  const int c = blockIdx.y * BN_CH + tx * 4;
+  if (c >= C) return;
+  float sc[4], sf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = rstd[c + j] * (gamma ? gamma[c + j] : 1.f);
+    sf[j] = (beta ? beta[c + j] : 0.f) - mean[c + j] * sc[j];
+  }
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(R, r0 + rows_per_chunk);
+  const size_t n = (size_t)R * C;
+  for (int r = r0 + ty; r < r1; r += BN_TY) {
+    const size_t off = (size_t)r * C + c;
+    const vp_f32x4 v = *reinterpret_cast<const vp_f32x4*>(x + off);
+    vp_f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = act_apply(v[j] * sc[j] + sf[j], act, slope);
+    if (y) *reinterpret_cast<vp_f32x4*>(y + off) = o;
+    if (y_split) store_split4(y_split, n, off, o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __restrict__ x, const float* dy,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                                                               float* dx, u16_t* __restrict__ dx_split, int R, int C,
+                                                               int rows_per_chunk, float invR, int act, float slope) {
+  const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
+  const int c = blockIdx.y * BN_CH + tx * 4;
+  if (c >= C) return;
+  float mu[4], rs[4], ga[4], be[4], k0[4], k1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = mean[c + j]; rs[j] = rstd[c + j];
+    ga[j] = gamma ? gamma[c + j] : 1.f; be[j] = beta ? beta[c + j] : 0.f;
+    k0[j] = sum_g[c + j] * invR; k1[j] = sum_gx[c + j] * invR;
+  }
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(R, r0 + rows_per_chunk);
+  const size_t n = (size_t)R * C;
+  for (int r = r0 + ty; r < r1; r += BN_TY) {
+    const size_t off = (size_t)r * C + c;
+    const vp_f32x4 xv = *reinterpret_cast<const vp_f32x4*>(x + off);
+    const vp_f32x4 dv = *reinterpret_cast<const vp_f32x4*>(dy + off);
+    vp_f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xv[j] - mu[j]) * rs[j];
+      const float g = dv[j] * act_grad_pre(ga[j] * xh + be[j], act, slope);
+      o[j] = ga[j] * rs[j] * (g - (k0[j] + xh * k1[j]));
+    }
+    if (dx) *reinterpret_cast<vp_f32x4*>(dx + off) = o;
+    if (dx_split) store_split4(dx_split, n, off, o[0], o[1], o[2], o[3]);
+  }
+}
+
+// elementwise passes want more, smaller chunks than the reductions (no partial slabs to combine)
+inline BnGrid bn_apply_grid(int R, int C) {
+  BnGrid g;
+  g.chunks_c = (C + BN_CH - 1) / BN_CH;
+  int want = 4096 / g.chunks_c;
+  if (want < 1) want = 1;
+  int maxr = (R + BN_TY - 1) / BN_TY;
+  g.chunks_r = want < maxr ? want : maxr;
+  if (g.chunks_r < 1) g.chunks_r = 1;
+  g.rows_per_chunk = (R + g.chunks_r - 1) / g.chunks_r;
+  g.chunks_r = (R + g.rows_per_chunk - 1) / g.rows_per_chunk;
+  return g;
 }
 
 inline size_t bn_ws_floats(int R, int C) {
@@ -290,19 +373,38 @@ int vp_bn_stats_f32(const float* x, int R, int C, float eps, float momentum, flo
   return check_launch("vp_bn_stats_f32(final)");
 }
 
-int vp_bn_act_fwd_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
-                      int R, int C, int act, float slope, vp_stream stream) {
-  VP_REQUIRE(x && mean && rstd && y && R > 0 && C > 0, "vp_bn_act_fwd_f32: bad arguments");
+static int bn_act_fwd_impl(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                           void* y_split, int R, int C, int act, float slope, vp_stream stream) {
+  VP_REQUIRE(x && mean && rstd && (y || y_split) && R > 0 && C > 0, "vp_bn_act_fwd: bad arguments");
+  VP_REQUIRE(!y_split || C % 4 == 0, "vp_bn_act_fwd_split_f32: C must be a multiple of 4");
   const size_t n = (size_t)R * C;
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
-                     beta, y, n, C, act, slope);
-  return check_launch("vp_bn_act_fwd_f32");
+  if (C % 4 == 0) {
+    BnGrid g = bn_apply_grid(R, C);
+    hipLaunchKernelGGL(bn_act_fwd_tiled_kernel, dim3(g.chunks_r, g.chunks_c), dim3(256), 0, (hipStream_t)stream, x, mean, rstd,
+                       gamma, beta, y, (u16_t*)y_split, R, C, g.rows_per_chunk, act, slope);
+  } else {
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
+                       beta, y, n, C, act, slope, (u16_t*)y_split);
+  }
+  return check_launch("vp_bn_act_fwd");
 }
 
-int vp_bn_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                      const float* beta, float* dx, float* dgamma, float* dbeta, int R, int C, int act, float slope,
-                      int batch_stats, void* ws, size_t ws_bytes, vp_stream stream) {
-  VP_REQUIRE(x && dy && mean && rstd && dx && ws && R > 0 && C > 0, "vp_bn_act_bwd_f32: bad arguments");
+int vp_bn_act_fwd_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                      int R, int C, int act, float slope, vp_stream stream) {
+  VP_REQUIRE(y, "vp_bn_act_fwd_f32: y is null");
+  return bn_act_fwd_impl(x, mean, rstd, gamma, beta, y, nullptr, R, C, act, slope, stream);
+}
+
+int vp_bn_act_fwd_split_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            float* y, void* y_split, int R, int C, int act, float slope, vp_stream stream) {
+  return bn_act_fwd_impl(x, mean, rstd, gamma, beta, y, y_split, R, C, act, slope, stream);
+}
+
+static int bn_act_bwd_impl(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta, int R, int C, int act,
+                           float slope, int batch_stats, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(x && dy && mean && rstd && (dx || dx_split) && ws && R > 0 && C > 0, "vp_bn_act_bwd_f32: bad arguments");
+  VP_REQUIRE(!dx_split || C % 4 == 0, "vp_bn_act_bwd_split_f32: C must be a multiple of 4");
   if (ws_bytes < vp_bn_workspace_bytes(R, C)) return fail(VP_ERR_WORKSPACE, "vp_bn_act_bwd_f32: workspace too small");
   BnGrid g = bn_grid(R, C);
   hipStream_t s = (hipStream_t)stream;
@@ -319,9 +421,28 @@ int vp_bn_act_bwd_f32(const float* x, const float* dy, const float* mean, const 
   if (rc) return rc;
   const size_t n = (size_t)R * C;
   const float invR = batch_stats ? 1.f / (float)R : 0.f;
-  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
-                     (const float*)sum_g, (const float*)sum_gx, dx, n, C, invR, act, slope);
+  if (C % 4 == 0) {
+    BnGrid ga = bn_apply_grid(R, C);
+    hipLaunchKernelGGL(bn_act_bwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
+                       (const float*)sum_g, (const float*)sum_gx, dx, (u16_t*)dx_split, R, C, ga.rows_per_chunk, invR, act, slope);
+  } else {
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
+                       (const float*)sum_g, (const float*)sum_gx, dx, n, C, invR, act, slope, (u16_t*)dx_split);
+  }
   return check_launch("vp_bn_act_bwd_f32(apply)");
+}
+
+int vp_bn_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, float* dx, float* dgamma, float* dbeta, int R, int C, int act, float slope,
+                      int batch_stats, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(dx, "vp_bn_act_bwd_f32: dx is null");
+  return bn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, dx, nullptr, dgamma, dbeta, R, C, act, slope, batch_stats, ws, ws_bytes, stream);
+}
+
+int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta, int R, int C, int act,
+                            float slope, int batch_stats, void* ws, size_t ws_bytes, vp_stream stream) {
+  return bn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, dx, dx_split, dgamma, dbeta, R, C, act, slope, batch_stats, ws, ws_bytes, stream);
 }
 
 int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream) {

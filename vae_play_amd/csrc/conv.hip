@@ -5,20 +5,6 @@
 
 namespace vp {
 
-// w_ref[Cs][Cb][25] -> p0[Cs][25][Cb], p1[Cb][25][Cs].  One thread per element of w_ref; reads
-// are coalesced, the two scattered writes are absorbed by L2 (weights are <= 26 MB).
-__global__ void pack_w5_kernel(const float* __restrict__ w, float* __restrict__ p0, float* __restrict__ p1, int Cs, int Cb) {
-  const size_t n = (size_t)Cs * Cb * kTaps;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i % kTaps);
-    const size_t sc = i / kTaps;
-    const int cb = (int)(sc % Cb), cs = (int)(sc / Cb);
-    const float v = w[i];
-    if (p0) p0[((size_t)cs * kTaps + t) * Cb + cb] = v;
-    if (p1) p1[((size_t)cb * kTaps + t) * Cs + cs] = v;
-  }
-}
-
 }  // namespace vp
 
 using namespace vp;
@@ -27,9 +13,8 @@ extern "C" {
 
 int vp_pack_w5_f32(const float* w_ref, float* p0, float* p1, int Csmall, int Cbig, vp_stream stream) {
   VP_REQUIRE(w_ref && (p0 || p1) && Csmall > 0 && Cbig > 0, "vp_pack_w5_f32: bad arguments");
-  const size_t n = (size_t)Csmall * Cbig * kTaps;
-  hipLaunchKernelGGL(pack_w5_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w_ref, p0, p1, Csmall, Cbig);
-  return check_launch("vp_pack_w5_f32");
+  VP_REQUIRE(Csmall <= 65535 && Cbig <= 65535, "vp_pack_w5_f32: channel count too large");
+  return pack_w5_f32_launch(w_ref, p0, p1, Csmall, Cbig, (hipStream_t)stream);
 }
 
 int vp_conv5_gather_f32(const float* big, const float* w_p0, const float* bias, float* small_out, int B, int Hs, int Ws,

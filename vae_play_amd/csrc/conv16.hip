@@ -1,0 +1,147 @@
+// Split-bf16 ("bf16x3") convolution families: C ABI + the producers of split planes.
+#include "common.h"
+#include "igemm16.h"
+#include "narrow.h"
+#include "split.h"
+
+namespace vp {
+
+__global__ void split_kernel(const float* __restrict__ x, u16_t* __restrict__ out, size_t n) {
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const vp_f32x4 v = *reinterpret_cast<const vp_f32x4*>(x + i * 4);
+    store_split4(out, n, i * 4, v[0], v[1], v[2], v[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    u16_t h, l;
+    split_f32(x[i], h, l);
+    out[i] = h;
+    out[n + i] = l;
+  }
+}
+
+// Weight re-pack through LDS so that both the fp32 reads and the packed writes are contiguous.
+//   MODE 0: p0[cs][t][cb] <- w[cs][cb][t]   (one cs, 64 cb per workgroup: 1600 contiguous floats in)
+//   MODE 1: p1[cb][t][cs] <- w[cs][cb][t]   (one cb, 64 cs per workgroup: 64 x 100-B segments in)
+// SPLIT: write bf16 hi/lo planes (plane stride n) instead of fp32.
+template <int MODE, bool SPLIT>
+__global__ void __launch_bounds__(256) pack_w5_tiled_kernel(const float* __restrict__ w, void* __restrict__ outv, int Cs, int Cb) {
+  __shared__ float tile[64][kTaps + 1];
+  const size_t n = (size_t)Cs * Cb * kTaps;
+  const int fixed = blockIdx.x, j0 = blockIdx.y * 64;
+  const int lim = (MODE == 0 ? Cb : Cs) - j0;           // valid entries of the 64-wide tile
+  for (int idx = threadIdx.x; idx < 64 * kTaps; idx += 256) {
+    const int j = idx / kTaps, t = idx - j * kTaps;
+    if (j < lim) {
+      const size_t src = MODE == 0 ? ((size_t)fixed * Cb + j0 + j) * kTaps + t : ((size_t)(j0 + j) * Cb + fixed) * kTaps + t;
+      tile[j][t] = w[src];
+    }
+  }
+  __syncthreads();
+  const int inner = MODE == 0 ? Cb : Cs;
+  for (int idx = threadIdx.x; idx < 64 * kTaps; idx += 256) {
+    const int t = idx >> 6, j = idx & 63;
+    if (j < lim) {
+      const size_t o = ((size_t)fixed * kTaps + t) * inner + j0 + j;
+      const float v = tile[j][t];
+      if constexpr (SPLIT) {
+        u16_t h, l;
+        split_f32(v, h, l);
+        ((u16_t*)outv)[o] = h;
+        ((u16_t*)outv)[n + o] = l;
+      } else {
+        ((float*)outv)[o] = v;
+      }
+    }
+  }
+}
+
+template <bool SPLIT>
+static int pack_w5_launch(const float* w, void* p0, void* p1, int Cs, int Cb, hipStream_t s, const char* what) {
+  if (p0) hipLaunchKernelGGL((pack_w5_tiled_kernel<0, SPLIT>), dim3(Cs, (Cb + 63) / 64), dim3(256), 0, s, w, p0, Cs, Cb);
+  if (p1) hipLaunchKernelGGL((pack_w5_tiled_kernel<1, SPLIT>), dim3(Cb, (Cs + 63) / 64), dim3(256), 0, s, w, p1, Cs, Cb);
+  return check_launch(what);
+}
+
+int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hipStream_t s) {
+  return pack_w5_launch<false>(w, p0, p1, Cs, Cb, s, "vp_pack_w5_f32");
+}
+
+}  // namespace vp
+
+using namespace vp;
+
+extern "C" {
+
+int vp_split_f32(const float* x, void* out_split, size_t n, vp_stream stream) {
+  VP_REQUIRE(x && out_split && n > 0, "vp_split_f32: bad arguments");
+  VP_REQUIRE((n & 3) == 0 || true, "unreachable");
+  hipLaunchKernelGGL(split_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, (u16_t*)out_split, n);
+  return check_launch("vp_split_f32");
+}
+
+int vp_pack_w5_split(const float* w_ref, void* p0_split, void* p1_split, int Csmall, int Cbig, vp_stream stream) {
+  VP_REQUIRE(w_ref && (p0_split || p1_split) && Csmall > 0 && Cbig > 0, "vp_pack_w5_split: bad arguments");
+  VP_REQUIRE(Csmall <= 65535 && Cbig <= 65535, "vp_pack_w5_split: channel count too large");
+  return pack_w5_launch<true>(w_ref, p0_split, p1_split, Csmall, Cbig, (hipStream_t)stream, "vp_pack_w5_split");
+}
+
+int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs,
+                           int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream) {
+  VP_REQUIRE(big_split && w_p0_split && small_out, "vp_conv5_gather_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Cbig % 8 == 0, "vp_conv5_gather_bf16x3: Cbig must be a multiple of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_gather_bf16x3: stride must be 1 or 2");
+  VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv5_gather_bf16x3: epilogue supports none|sigmoid");
+  ProbF16 p;
+  p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  p.big = (const u16*)big_split; p.big_plane = (size_t)B * p.g.Hb * p.g.Wb * Cbig;
+  p.w = (const u16*)w_p0_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
+  p.bias = bias; p.out = small_out; p.act = act;
+  p.M = B * Hs * Ws; p.N = Csmall; p.K = kTaps * Cbig;
+  launch_igemm16(p, p.M, p.N, 1, (hipStream_t)stream);
+  return check_launch("vp_conv5_gather_bf16x3");
+}
+
+int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Csmall,
+                            int Cbig, int stride, vp_stream stream) {
+  VP_REQUIRE(small_split && w_p1_split && big_out, "vp_conv5_scatter_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Csmall % 8 == 0, "vp_conv5_scatter_bf16x3: Csmall must be a multiple of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_scatter_bf16x3: stride must be 1 or 2");
+  ProbT16 p;
+  p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
+  p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
+  p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
+  launch_igemm16(p, p.M, p.N, stride * stride, (hipStream_t)stream);
+  return check_launch("vp_conv5_scatter_bf16x3");
+}
+
+size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  return wgrad_slab_floats(g, wgrad_nsplit(g)) * sizeof(float);
+}
+
+int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,
+                          int Csmall, int stride, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(big_split && small_split && dw_ref && ws, "vp_conv5_wgrad_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig % 8 == 0 && Csmall % 8 == 0 && Cbig > 0 && Csmall > 0,
+             "vp_conv5_wgrad_bf16x3: channel counts must be multiples of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_wgrad_bf16x3: stride must be 1 or 2");
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
+  const int ns = wgrad_nsplit(g);
+  if (ws_bytes < wgrad_slab_floats(g, ns) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_wgrad_bf16x3: workspace too small");
+  ProbW16 p;
+  p.g = g;
+  p.big = (const u16*)big_split; p.big_plane = (size_t)B * g.Hb * g.Wb * Cbig;
+  p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
+  p.slab = (float*)ws; p.M = Csmall; p.N = Cbig; p.K = B * Hs * Ws;
+  p.nsplit = ns;
+  const int per = (p.K + ns - 1) / ns;
+  p.k_per_split = ((per + 31) / 32) * 32;
+  launch_igemm16(p, p.M, p.N, kTaps * ns, (hipStream_t)stream);
+  int rc = check_launch("vp_conv5_wgrad_bf16x3(main)");
+  if (rc) return rc;
+  return slab_reduce_launch((const float*)ws, dw_ref, Csmall, Cbig, ns, (hipStream_t)stream);
+}
+}

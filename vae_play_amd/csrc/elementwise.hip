@@ -2,11 +2,13 @@
 // wavefront reductions, and the fused flat-arena optimiser steps.
 #include "common.h"
 #include "problems.h"
+#include "split.h"
 
 namespace vp {
 
 // out[b][c][r] = in[b][r][c]  (32x32 LDS tile, +1 pad: conflict-free for ds_read_b32 columns)
-__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
+                                 u16_t* __restrict__ out_split, size_t plane) {
   __shared__ float tile[32][33];
   const size_t base = (size_t)blockIdx.z * rows * cols;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -17,16 +19,27 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
   __syncthreads();
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     const int c = c0 + j, r = r0 + threadIdx.x;
-    if (r < rows && c < cols) out[base + (size_t)c * rows + r] = tile[threadIdx.x][j];
+    if (r < rows && c < cols) {
+      const float v = tile[threadIdx.x][j];
+      const size_t o = base + (size_t)c * rows + r;
+      if (out) out[o] = v;
+      if (out_split) {
+        u16_t h, l;
+        split_f32(v, h, l);
+        out_split[o] = h;
+        out_split[plane + o] = l;
+      }
+    }
   }
 }
 
-inline int launch_transpose(const float* in, float* out, int B, int rows, int cols, hipStream_t s, const char* what) {
-  VP_REQUIRE(in && out && B > 0 && rows > 0 && cols > 0, "%s: bad arguments", what);
+inline int launch_transpose(const float* in, float* out, int B, int rows, int cols, hipStream_t s, const char* what,
+                            void* out_split = nullptr) {
+  VP_REQUIRE(in && (out || out_split) && B > 0 && rows > 0 && cols > 0, "%s: bad arguments", what);
   VP_REQUIRE(B <= 65535, "%s: batch > 65535", what);
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, B);
   VP_REQUIRE(grid.y <= 65535, "%s: too many row tiles", what);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, out, rows, cols);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, out, rows, cols, (u16_t*)out_split, (size_t)B * rows * cols);
   return check_launch(what);
 }
 
@@ -186,6 +199,9 @@ const char* vp_last_error(void) { return err_buf(); }
 
 int vp_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, vp_stream stream) {
   return launch_transpose(in, out, B, C, H * W, (hipStream_t)stream, "vp_nchw_to_nhwc_f32");
+}
+int vp_nchw_to_nhwc_split_f32(const float* in, float* out, void* out_split, int B, int C, int H, int W, vp_stream stream) {
+  return launch_transpose(in, out, B, C, H * W, (hipStream_t)stream, "vp_nchw_to_nhwc_split_f32", out_split);
 }
 int vp_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, vp_stream stream) {
   return launch_transpose(in, out, B, H * W, C, (hipStream_t)stream, "vp_nhwc_to_nchw_f32");

@@ -31,12 +31,13 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __rest
   }
 }
 
+// one wavefront per channel: the 64 lanes split the chunk partials, fp64 wave reduction
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int nchunk) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int k = 0; k < nchunk; ++k) s += (double)partial[(size_t)k * C + c];
-  out[c] = (float)s;
+  for (int k = threadIdx.x; k < nchunk; k += 64) s += (double)partial[(size_t)k * C + c];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 inline int colsum_chunks(int R) {
@@ -97,7 +98,7 @@ int vp_colsum_f32(const float* x, float* out, int R, int C, void* ws, size_t ws_
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk), dim3(64, 4), 0, s, x, (float*)ws, R, C, rpc);
   int rc = check_launch("vp_colsum_f32(partial)");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)ws, out, C, nchunk);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, s, (const float*)ws, out, C, nchunk);
   return check_launch("vp_colsum_f32(final)");
 }
 }

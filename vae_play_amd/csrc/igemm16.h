@@ -1,0 +1,380 @@
+// Split-bf16 ("bf16x3") implicit-GEMM kernel for gfx950.
+//
+// fp32 operands are stored as two bf16 planes, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+// (16 significant bits, fp32 exponent range).  A product is contracted as
+//      a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi          (the 2^-18 lo*lo term is dropped)
+// with three v_mfma_f32_32x32x16_bf16 per fragment pair and fp32 accumulation: ~5e-6 relative
+// error per contraction (plain bf16: 2e-3, outside the 1e-3 parity bar) at a 5.3x higher MFMA
+// ceiling than v_mfma_f32_32x32x2_f32 (2.5 PFLOP/s / 3 vs 157 TFLOP/s).
+//
+//  * planes are written by the producers (BN/activation, transposes, weight packing), never by
+//    this kernel: the GEMM only moves 16-B chunks of 8 bf16 and issues MFMAs;
+//  * 4 wavefronts per workgroup, K-tile of 32 elements (two 16-deep MFMA steps);
+//  * "MK" operands (k contiguous in HBM: activations gathered per tap, packed weights):
+//    LDS image [row][32 bf16 + 16 B pad] (80-B stride: a 16-lane ds_read_b128 group covers all 64
+//    banks), fragment = one ds_read_b128 per tile and step;
+//  * "KM" operands (the weight-gradient GEMM contracts over pixels, which are the SLOW index of
+//    an NHWC tensor): LDS image [pixel][channels] with the row stride == 16 dwords (mod 64) and the
+//    fragment fetched with the hardware transposing read ds_read_b64_tr_b16 (two per tile and
+//    step), so no transpose pass through HBM or VALU is needed;
+//  * accumulator layout and store path identical to igemm.h (lane = output channel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "problems.h"
+
+namespace vp {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+constexpr int BK16 = 32;              // elements per K-tile
+constexpr int MK_STRIDE_B = 80;       // bytes per MK row: 64 data + 16 pad
+
+VP_HD u32x4_t zero_u4() { u32x4_t z = {0u, 0u, 0u, 0u}; return z; }
+VP_HD u32x4_t ld16(const u16* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *reinterpret_cast<const u32x4_t*>(p);
+#else
+  u32x4_t v; __builtin_memcpy(&v, p, 16); return v;
+#endif
+}
+
+// row stride (bytes) of a KM image with BR channel columns: data + pad, == 64 B (mod 256 B)
+template <int BR>
+struct KmStride {
+  static constexpr int bytes = (BR == 128) ? 320 : (BR == 64 ? 192 : (BR == 32 ? 64 : -1));
+};
+template <int BR, bool KM>
+struct Lds16 {
+  static constexpr int plane_bytes = KM ? BK16 * KmStride<BR>::bytes : BR * MK_STRIDE_B;
+};
+
+// ---- problem descriptors (vector path only: channel counts are multiples of 8) -----------------
+// F family on split planes: A(m=(b,hs,ws), k=(tap,c)) = big[...]; B(n, k) = wp0[n][tap][c]
+struct ProbF16 {
+  static constexpr bool A_KM = false, B_KM = false;
+  const u16* big; size_t big_plane;     // hi plane at big, lo plane at big + big_plane (elements)
+  const u16* w; size_t w_plane;         // packed P0 planes [Cs][25][Cb]
+  const float* bias; float* out;
+  ConvGeom g; int act; int M, N, K;
+  struct ZCtx { int k_begin, k_end; };
+  struct ARow { int pix_base, h0, w0, valid; };
+  struct BRow { int off, valid; };
+  VP_HD void z_setup(int, ZCtx& z) const { z.k_begin = 0; z.k_end = K; }
+  VP_HD ARow a_row(int m, const ZCtx&) const {
+    ARow r; r.valid = m < M; int mm = r.valid ? m : 0;
+    int b = mm / (g.Hs * g.Ws); int rem = mm - b * (g.Hs * g.Ws);
+    int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+    r.pix_base = b * g.Hb * g.Wb; r.h0 = g.stride * hs - 2; r.w0 = g.stride * ws - 2;
+    return r;
+  }
+  VP_HD u32x4_t a_load(const ARow& r, int k, int plane, const ZCtx&) const {
+    if (!r.valid || k >= K) return zero_u4();
+    int tap = k / g.Cb, c = k - tap * g.Cb;
+    int rr = tap / 5, qq = tap - rr * 5;
+    int h = r.h0 + rr, w_ = r.w0 + qq;
+    if (h < 0 || h >= g.Hb || w_ < 0 || w_ >= g.Wb) return zero_u4();
+    return ld16(big + plane * big_plane + (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c);
+  }
+  VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * K; return r; }
+  VP_HD u32x4_t b_load(const BRow& r, int k, int plane, const ZCtx&) const {
+    if (!r.valid || k >= K) return zero_u4();
+    return ld16(w + plane * w_plane + (size_t)r.off + k);
+  }
+  VP_HD void store(int m, int n, float v, const ZCtx&) const {
+    if (m >= M || n >= N) return;
+    if (bias) v += bias[n];
+    if (act == ACT_SIGMOID) v = 1.f / (1.f + __builtin_expf(-v));
+    out[(size_t)m * N + n] = v;
+  }
+};
+
+// T family on split planes (phase-decomposed transposed conv)
+struct ProbT16 {
+  static constexpr bool A_KM = false, B_KM = false;
+  const u16* small; size_t small_plane;
+  const u16* w; size_t w_plane;          // packed P1 planes [Cb][25][Cs]
+  float* out; ConvGeom g; int M, N;
+  struct ZCtx { int k_begin, k_end, ph, pw, th, tw; };
+  struct ARow { int pix_base, q, p, valid; };
+  struct BRow { int off, valid; };
+  VP_HD void z_setup(int zi, ZCtx& z) const {
+    int s = g.stride; z.ph = zi / s; z.pw = zi - z.ph * s;
+    z.th = (5 - z.ph + s - 1) / s; z.tw = (5 - z.pw + s - 1) / s;
+    z.k_begin = 0; z.k_end = z.th * z.tw * g.Cs;
+  }
+  VP_HD ARow a_row(int m, const ZCtx&) const {
+    ARow r; r.valid = m < M; int mm = r.valid ? m : 0;
+    int b = mm / (g.Hs * g.Ws); int rem = mm - b * (g.Hs * g.Ws);
+    r.q = rem / g.Ws; r.p = rem - r.q * g.Ws; r.pix_base = b * g.Hs * g.Ws;
+    return r;
+  }
+  VP_HD u32x4_t a_load(const ARow& r, int k, int plane, const ZCtx& z) const {
+    if (!r.valid || k >= z.k_end) return zero_u4();
+    int t = k / g.Cs, c = k - t * g.Cs;
+    int rp = t / z.tw, qp = t - rp * z.tw;
+    int d0 = 2 / g.stride;
+    int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+    if (h < 0 || h >= g.Hs || w_ < 0 || w_ >= g.Ws) return zero_u4();
+    return ld16(small + plane * small_plane + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c);
+  }
+  VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * kTaps * g.Cs; return r; }
+  VP_HD u32x4_t b_load(const BRow& r, int k, int plane, const ZCtx& z) const {
+    if (!r.valid || k >= z.k_end) return zero_u4();
+    int t = k / g.Cs, c = k - t * g.Cs;
+    int rp = t / z.tw, qp = t - rp * z.tw;
+    int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+    return ld16(w + plane * w_plane + (size_t)r.off + tap * g.Cs + c);
+  }
+  VP_HD void store(int m, int n, float v, const ZCtx& z) const {
+    if (m >= M || n >= N) return;
+    int b = m / (g.Hs * g.Ws); int rem = m - b * (g.Hs * g.Ws);
+    int q = rem / g.Ws, p = rem - q * g.Ws;
+    int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
+    out[((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n] = v;
+  }
+};
+
+// W family on split planes: slab[split][tap][cs][cb]; both operands pixel-major (KM)
+struct ProbW16 {
+  static constexpr bool A_KM = true, B_KM = true;
+  const u16* big; size_t big_plane;
+  const u16* small; size_t small_plane;
+  float* slab; ConvGeom g; int M, N, K; int nsplit, k_per_split;
+  struct ZCtx { int k_begin, k_end, rr, qq, tap, split; };
+  VP_HD void z_setup(int zi, ZCtx& z) const {
+    z.tap = zi / nsplit; z.split = zi - z.tap * nsplit;
+    z.rr = z.tap / 5; z.qq = z.tap - z.rr * 5;
+    z.k_begin = z.split * k_per_split;
+    int e = z.k_begin + k_per_split; z.k_end = e < K ? e : K;
+  }
+  VP_HD u32x4_t a_load_km(int k, int m, int plane, const ZCtx& z) const {   // small[pixel k][m..m+7]
+    if (k >= z.k_end || m >= M) return zero_u4();
+    return ld16(small + plane * small_plane + (size_t)k * g.Cs + m);
+  }
+  VP_HD u32x4_t b_load_km(int k, int n, int plane, const ZCtx& z) const {   // big[shifted pixel][n..n+7]
+    if (k >= z.k_end || n >= N) return zero_u4();
+    int b = k / (g.Hs * g.Ws); int rem = k - b * (g.Hs * g.Ws);
+    int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+    int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
+    if (h < 0 || h >= g.Hb || w_ < 0 || w_ >= g.Wb) return zero_u4();
+    return ld16(big + plane * big_plane + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb + n);
+  }
+  VP_HD void store(int m, int n, float v, const ZCtx& z) const {
+    if (m >= M || n >= N) return;
+    slab[(((size_t)z.split * kTaps + z.tap) * M + m) * N + n] = v;
+  }
+};
+
+#if defined(__HIPCC__)
+
+template <class P, int NR, bool KM> struct Rows16A;
+template <class P, int NR> struct Rows16A<P, NR, false> { typename P::ARow r[NR]; };
+template <class P, int NR> struct Rows16A<P, NR, true> {};
+template <class P, int NR, bool KM> struct Rows16B;
+template <class P, int NR> struct Rows16B<P, NR, false> { typename P::BRow r[NR]; };
+template <class P, int NR> struct Rows16B<P, NR, true> {};
+
+// fragment fetch: 8 bf16 (k = 8*lh .. 8*lh+7 of MFMA step s) of tile row/column `row`
+template <int BR, bool KM>
+__device__ __forceinline__ bf16x8_t frag16(const unsigned char* plane, int row, int s, int li, int lh, int lane) {
+  if constexpr (!KM) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(plane + row * MK_STRIDE_B + s * 32 + lh * 16);
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    // transposing read: within a 16-lane group, lane i supplies &T[k0 + (i>>2)][col0 + 4*(i&3)] and
+    // receives column i of the 4 rows.  col0 = row - (li & 15): the group's first column.
+    constexpr int S = KmStride<BR>::bytes;
+    const int i = lane & 15;
+    const int col0 = row - i;
+    const int k0 = s * 16 + lh * 8;
+    const unsigned char* p0 = plane + (k0 + (i >> 2)) * S + (col0 + 4 * (i & 3)) * 2;
+    typedef bf16x4_t __attribute__((address_space(3))) * lds_v4;
+    const bf16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(p0));
+    const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(p0 + 4 * S));
+    return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+template <class P, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
+  constexpr int NA = BM / 32, NB = BN / 32;   // 16-B chunks per thread per K-tile (both planes)
+  constexpr int A_PLANE = Lds16<BM, P::A_KM>::plane_bytes;
+  constexpr int B_PLANE = Lds16<BN, P::B_KM>::plane_bytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_PLANE + 2 * B_PLANE];
+  unsigned char* As = lds;                   // [plane][...]
+  unsigned char* Bs = lds + 2 * A_PLANE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  typename P::ZCtx z;
+  p.z_setup(blockIdx.z, z);
+
+  // staging map.  MK: chunk = (row = tid/8 + 32*i, sub = tid%8 -> plane = sub/4, k8 = sub%4)
+  //               KM: chunk = (krow, col8, plane) with V = BR/8 chunks per k-row and plane
+  Rows16A<P, NA, P::A_KM> ra;
+  Rows16B<P, NB, P::B_KM> rb;
+  if constexpr (!P::A_KM) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra.r[i] = p.a_row(m0 + (tid >> 3) + 32 * i, z);
+  }
+  if constexpr (!P::B_KM) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb.r[i] = p.b_row(n0 + (tid >> 3) + 32 * i, z);
+  }
+  u32x4_t sa[NA], sb[NB];
+
+  auto stage_load = [&](int k0) {
+    if constexpr (!P::A_KM) {
+      const int plane = (tid & 7) >> 2, k8 = (tid & 3) * 8;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) sa[i] = p.a_load(ra.r[i], k0 + k8, plane, z);
+    } else {
+      constexpr int V = BM / 8;                 // chunks per k-row per plane
+      constexpr int PER = 2 * V;                // chunks per k-row (both planes)
+      constexpr int RP = 256 / PER;             // k-rows per pass
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int kr = tid / PER + RP * i, sub = tid % PER;
+        sa[i] = p.a_load_km(k0 + kr, m0 + (sub % V) * 8, sub / V, z);
+      }
+    }
+    if constexpr (!P::B_KM) {
+      const int plane = (tid & 7) >> 2, k8 = (tid & 3) * 8;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) sb[i] = p.b_load(rb.r[i], k0 + k8, plane, z);
+    } else {
+      constexpr int V = BN / 8, PER = 2 * V, RP = 256 / PER;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int kr = tid / PER + RP * i, sub = tid % PER;
+        sb[i] = p.b_load_km(k0 + kr, n0 + (sub % V) * 8, sub / V, z);
+      }
+    }
+  };
+  auto stage_write = [&]() {
+    if constexpr (!P::A_KM) {
+      const int plane = (tid & 7) >> 2, k8 = (tid & 3);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        *reinterpret_cast<u32x4_t*>(As + plane * A_PLANE + ((tid >> 3) + 32 * i) * MK_STRIDE_B + k8 * 16) = sa[i];
+    } else {
+      constexpr int V = BM / 8, PER = 2 * V, RP = 256 / PER, S = KmStride<BM>::bytes;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int kr = tid / PER + RP * i, sub = tid % PER;
+        *reinterpret_cast<u32x4_t*>(As + (sub / V) * A_PLANE + kr * S + (sub % V) * 16) = sa[i];
+      }
+    }
+    if constexpr (!P::B_KM) {
+      const int plane = (tid & 7) >> 2, k8 = (tid & 3);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        *reinterpret_cast<u32x4_t*>(Bs + plane * B_PLANE + ((tid >> 3) + 32 * i) * MK_STRIDE_B + k8 * 16) = sb[i];
+    } else {
+      constexpr int V = BN / 8, PER = 2 * V, RP = 256 / PER, S = KmStride<BN>::bytes;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int kr = tid / PER + RP * i, sub = tid % PER;
+        *reinterpret_cast<u32x4_t*>(Bs + (sub / V) * B_PLANE + kr * S + (sub % V) * 16) = sb[i];
+      }
+    }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int klen = z.k_end - z.k_begin;
+  const int nk = klen > 0 ? (klen + BK16 - 1) / BK16 : 0;
+  const int arow0 = wm * (BM / WM) + li;
+  const int brow0 = wn * (BN / WN) + li;
+
+  if (nk > 0) {
+    stage_load(z.k_begin);
+    stage_write();
+    __syncthreads();
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) stage_load(z.k_begin + (kt + 1) * BK16);
+#pragma unroll
+    for (int s = 0; s < BK16 / 16; ++s) {
+      bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = frag16<BM, P::A_KM>(As, arow0 + 32 * i, s, li, lh, lane);
+        al[i] = frag16<BM, P::A_KM>(As + A_PLANE, arow0 + 32 * i, s, li, lh, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = frag16<BN, P::B_KM>(Bs, brow0 + 32 * j, s, li, lh, lane);
+        bl[j] = frag16<BN, P::B_KM>(Bs + B_PLANE, brow0 + 32 * j, s, li, lh, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (more) {
+      stage_write();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + wm * (BM / WM) + 32 * i + row;
+        const int n = n0 + wn * (BN / WN) + 32 * j + li;
+        p.store(m, n, acc[i][j][r], z);
+      }
+}
+
+struct Tile16 { int bm, bn; };
+inline Tile16 choose_tile16(long M, long N, int gz) {
+  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
+  if (M >= 128 && N >= 128 && blocks(128, 128) >= 384) return {128, 128};
+  if (M >= 128 && N >= 64 && blocks(128, 64) >= 384) return {128, 64};
+  return {64, 64};
+}
+
+template <class P>
+inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t stream) {
+  Tile16 t = choose_tile16(M, N, gz);
+  dim3 block(256);
+  auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
+  if (t.bm == 128 && t.bn == 128) {
+    hipLaunchKernelGGL((igemm16_kernel<P, 128, 128, 2, 2>), grid(128, 128), block, 0, stream, p);
+  } else if (t.bm == 128 && t.bn == 64) {
+    hipLaunchKernelGGL((igemm16_kernel<P, 128, 64, 2, 2>), grid(128, 64), block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((igemm16_kernel<P, 64, 64, 2, 2>), grid(64, 64), block, 0, stream, p);
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace vp

@@ -96,21 +96,33 @@ __global__ void __launch_bounds__(256) wgrad_narrow_small_kernel(const float* __
       const int hb = h + r - 2;
       if (hb < 0 || hb >= H) continue;   // wave-uniform
       const float* bp = big + ((size_t)(b * H + hb) * W) * Cb + c;
-      float w0 = 0.f, w1 = 0.f, w2 = bp[0], w3 = W > 1 ? bp[Cb] : 0.f, w4 = W > 2 ? bp[2 * (size_t)Cb] : 0.f;
-      for (int x = 0; x < W; ++x) {
-        float s[NS];
+      // sliding window over the row: win[j] = big[hb][x0 + j - 2]; four pixels per iteration so that four
+      // independent 256-B loads are in flight per wave (the one-pixel loop was latency-bound: 12 TFLOP/s)
+      float win[8];
+      win[0] = 0.f; win[1] = 0.f;
+      win[2] = bp[0];
+      win[3] = W > 1 ? bp[Cb] : 0.f;
+      for (int x0 = 0; x0 < W; x0 += 4) {
 #pragma unroll
-        for (int n = 0; n < NS; ++n) s[n] = sp[x * NS + n];
+        for (int j = 0; j < 4; ++j) win[4 + j] = (x0 + 2 + j < W) ? bp[(size_t)(x0 + 2 + j) * Cb] : 0.f;
 #pragma unroll
-        for (int n = 0; n < NS; ++n) {
-          acc[r * 5 + 0][n] = fmaf(w0, s[n], acc[r * 5 + 0][n]);
-          acc[r * 5 + 1][n] = fmaf(w1, s[n], acc[r * 5 + 1][n]);
-          acc[r * 5 + 2][n] = fmaf(w2, s[n], acc[r * 5 + 2][n]);
-          acc[r * 5 + 3][n] = fmaf(w3, s[n], acc[r * 5 + 3][n]);
-          acc[r * 5 + 4][n] = fmaf(w4, s[n], acc[r * 5 + 4][n]);
+        for (int j = 0; j < 4; ++j) {
+          if (x0 + j < W) {
+            float sv[NS];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) sv[n] = sp[(x0 + j) * NS + n];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+              acc[r * 5 + 0][n] = fmaf(win[j + 0], sv[n], acc[r * 5 + 0][n]);
+              acc[r * 5 + 1][n] = fmaf(win[j + 1], sv[n], acc[r * 5 + 1][n]);
+              acc[r * 5 + 2][n] = fmaf(win[j + 2], sv[n], acc[r * 5 + 2][n]);
+              acc[r * 5 + 3][n] = fmaf(win[j + 3], sv[n], acc[r * 5 + 3][n]);
+              acc[r * 5 + 4][n] = fmaf(win[j + 4], sv[n], acc[r * 5 + 4][n]);
+            }
+          }
         }
-        w0 = w1; w1 = w2; w2 = w3; w3 = w4;
-        w4 = (x + 3 < W) ? bp[(size_t)(x + 3) * Cb] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) win[j] = win[4 + j];
       }
     }
   }
@@ -225,7 +237,7 @@ int narrow_gather_launch(const float* big, const float* w_p0, const float* bias,
 
 static int narrow_rows_per_block(const ConvGeom& g) {
   const int rows = g.B * g.Hs;
-  int blocks = 512;
+  int blocks = 1024;
   int rpb = (rows + blocks - 1) / blocks;
   if (rpb < 4) rpb = 4;
   return rpb;

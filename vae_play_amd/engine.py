@@ -67,7 +67,15 @@ class FusedVAEStep:
     ``vae.parameters()`` (its gradient arena receives the gradients).
     """
 
-    def __init__(self, vae: VAE, optimizer, batch_size: int, img_size: int, channels: int, group=None):
+    def __init__(self, vae: VAE, optimizer, batch_size: int, img_size: int, channels: int, group=None,
+                 precision: str = "bf16x3"):
+        """precision: "f32"    -- every contraction on v_mfma_f32_32x32x2_f32 (exact fp32, ~1e-6 parity);
+                      "bf16x3" -- 5x5 convolutions whose channel counts are multiples of 8 run on the
+                                  split-bf16 kernel (3 bf16 MFMAs per product, fp32 accumulate, ~1e-5 parity);
+                                  edge layers and dense layers stay on the f32 kernels."""
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("precision must be 'f32' or 'bf16x3'")
+        self.precision = precision
         self.vae, self.opt, self.B, self.S, self.C = vae, optimizer, batch_size, img_size, channels
         self.Z, self.L = vae.z_size, vae.iter_level
         self.group = group
@@ -90,6 +98,12 @@ class FusedVAEStep:
     def _ws(self, name: str, nbytes: int) -> torch.Tensor:
         return self._buf(name, max(4, (nbytes + 3) // 4))
 
+    def _sbuf(self, name: str, n: int) -> torch.Tensor:
+        """split tensor: (2, n) int16 = bf16 hi plane + bf16 lo plane"""
+        t = torch.empty((2, n), dtype=torch.int16, device=self.dev)
+        self._bufs[name] = t
+        return t
+
     # ---- plan construction ------------------------------------------------------------------
     def _build(self):
         lib = _lib.load()
@@ -104,19 +118,25 @@ class FusedVAEStep:
                 raise _lib.VaePlayHipError("parameter has no arena gradient; build the optimiser first")
             return p.grad
 
-        def bn_block(tag, x_buf, R, Cn, bn_mod, y_buf):
-            """stats + fused normalise/ReLU; returns the saved (mean, rstd)."""
+        x3 = self.precision == "bf16x3"
+
+        def use16(cin, cout):
+            return x3 and cin % 8 == 0 and cout % 8 == 0
+
+        def bn_block(tag, x_buf, R, Cn, bn_mod, y_buf, y_split=None):
+            """stats + fused normalise/ReLU (fp32 and/or split output); returns the saved (mean, rstd)."""
             mean, rstd = self._buf(f"{tag}.mean", Cn), self._buf(f"{tag}.rstd", Cn)
             ws = self._ws(f"{tag}.bnws", lib.vp_bn_workspace_bytes(R, Cn))
             fwd.add("vp_bn_stats_f32", P(x_buf), R, Cn, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
                     P(bn_mod.running_var), P(ws), ws.numel() * 4)
-            fwd.add("vp_bn_act_fwd_f32", P(x_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(y_buf), R, Cn,
-                    _ACT_RELU, 0.0)
+            fwd.add("vp_bn_act_fwd_split_f32", P(x_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(y_buf),
+                    P(y_split), R, Cn, _ACT_RELU, 0.0)
             return mean, rstd, ws
 
-        def bn_block_bwd(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws):
-            bwd.add("vp_bn_act_bwd_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(dx_buf),
-                    P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1, P(ws), ws.numel() * 4)
+        def bn_block_bwd(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None):
+            bwd.add("vp_bn_act_bwd_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
+                    P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1,
+                    P(ws), ws.numel() * 4)
 
         # ---------------- forward ----------------
         self.x_nchw = self._buf("x_nchw", B, C, S, S)
@@ -129,20 +149,35 @@ class FusedVAEStep:
 
         enc_ch = [C] + [blk.conv.weight.shape[0] for blk in enc.conv]
         sp = [S // (2 ** i) for i in range(L + 1)]
-        enc_in = [x_nhwc]
+        enc16 = [use16(enc_ch[i], enc_ch[i + 1]) for i in range(L)]
+        enc_in = [x_nhwc]        # fp32 inputs (None when only the split copy exists)
+        enc_in_s = [None]        # split inputs
         enc_rec = []
         for i, blk in enumerate(enc.conv):
             Cin, Cout, Hs = enc_ch[i], enc_ch[i + 1], sp[i + 1]
-            p0 = self._buf(f"enc{i}.p0", Cout * 25 * Cin)
-            p1 = self._buf(f"enc{i}.p1", Cin * 25 * Cout) if i > 0 else None
-            fwd.add("vp_pack_w5_f32", P(blk.conv.weight), P(p0), P(p1), Cout, Cin)
-            c = self._buf(f"enc{i}.c", B * Hs * Hs * Cout)
-            a = self._buf(f"enc{i}.a", B * Hs * Hs * Cout)
-            fwd.add("vp_conv5_gather_f32", P(enc_in[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
-                    flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"enc{i}.fwd")
-            mean, rstd, ws = bn_block(f"enc{i}", c, B * Hs * Hs, Cout, blk.bn, a)
+            n_out = B * Hs * Hs * Cout
+            c = self._buf(f"enc{i}.c", n_out)
+            fl = 50.0 * B * Hs * Hs * Cin * Cout
+            if enc16[i]:
+                p0 = self._sbuf(f"enc{i}.p0s", Cout * 25 * Cin)
+                p1 = self._sbuf(f"enc{i}.p1s", Cin * 25 * Cout)
+                fwd.add("vp_pack_w5_split", P(blk.conv.weight), P(p0), P(p1), Cout, Cin)
+                fwd.add("vp_conv5_gather_bf16x3", P(enc_in_s[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
+                        flops=fl, tag=f"enc{i}.fwd")
+            else:
+                p0 = self._buf(f"enc{i}.p0", Cout * 25 * Cin)
+                p1 = self._buf(f"enc{i}.p1", Cin * 25 * Cout) if i > 0 else None
+                fwd.add("vp_pack_w5_f32", P(blk.conv.weight), P(p0), P(p1), Cout, Cin)
+                fwd.add("vp_conv5_gather_f32", P(enc_in[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
+                        flops=fl, tag=f"enc{i}.fwd")
+            # the activation feeds the next conv (+ its wgrad) or, for the last block, the flatten
+            nxt16 = i + 1 < L and enc16[i + 1]
+            a = None if nxt16 else self._buf(f"enc{i}.a", n_out)
+            a_s = self._sbuf(f"enc{i}.as", n_out) if nxt16 else None
+            mean, rstd, ws = bn_block(f"enc{i}", c, B * Hs * Hs, Cout, blk.bn, a, a_s)
             enc_rec.append((blk, Cin, Cout, Hs, p1, c, mean, rstd, ws))
             enc_in.append(a)
+            enc_in_s.append(a_s)
         size = enc_ch[-1]
         F0 = 64 * size
         flat = self._buf("enc.flat", B * F0)
@@ -168,25 +203,40 @@ class FusedVAEStep:
         ws_dfc = self._ws("dec.fc.ws", lib.vp_gemm_workspace_bytes(B, F1, Z))
         fwd.add("vp_gemm_f32", P(self.z), Z, 1, P(dfc_lin.weight), Z, 1, P(d), F1, None, B, F1, Z, 0, P(ws_dfc), ws_dfc.numel() * 4)
         d_mean, d_rstd, d_ws = bn_block("dec.fc", d, B, F1, dfc_bn, db)
-        dn = self._buf("dec.in", B * F1)
-        fwd.add("vp_nchw_to_nhwc_f32", P(db), P(dn), B, dsize, 8, 8)
+        dec_ch = [dsize] + [blk.conv.weight.shape[1] for blk in list(dec.conv)[:L]]
+        dec16 = [use16(dec_ch[i], dec_ch[i + 1]) for i in range(L)]
+        dn = None if dec16[0] else self._buf("dec.in", B * F1)
+        dn_s = self._sbuf("dec.in_s", B * F1) if dec16[0] else None
+        fwd.add("vp_nchw_to_nhwc_split_f32", P(db), P(dn), P(dn_s), B, dsize, 8, 8)
 
         dec_in = [dn]
+        dec_in_s = [dn_s]
         dec_rec = []
-        dec_ch = [dsize] + [blk.conv.weight.shape[1] for blk in list(dec.conv)[:L]]
         for i in range(L):
             blk = dec.conv[i]
             Cin, Cout, Hs = dec_ch[i], dec_ch[i + 1], 8 * (2 ** i)
-            p1 = self._buf(f"dec{i}.p1", Cout * 25 * Cin)   # T family: [Cbig=Cout][25][Csmall=Cin]
-            p0 = self._buf(f"dec{i}.p0", Cin * 25 * Cout)   # F family (dgrad): [Csmall=Cin][25][Cbig=Cout]
-            fwd.add("vp_pack_w5_f32", P(blk.conv.weight), P(p0), P(p1), Cin, Cout)
-            tbuf = self._buf(f"dec{i}.t", B * 4 * Hs * Hs * Cout)
-            u = self._buf(f"dec{i}.u", B * 4 * Hs * Hs * Cout)
-            fwd.add("vp_conv5_scatter_f32", P(dec_in[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
-                    flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"dec{i}.fwd")
-            mean, rstd, ws = bn_block(f"dec{i}", tbuf, B * 4 * Hs * Hs, Cout, blk.bn, u)
+            n_out = B * 4 * Hs * Hs * Cout
+            tbuf = self._buf(f"dec{i}.t", n_out)
+            fl = 50.0 * B * Hs * Hs * Cin * Cout
+            if dec16[i]:
+                p1 = self._sbuf(f"dec{i}.p1s", Cout * 25 * Cin)   # T family: [Cbig=Cout][25][Csmall=Cin]
+                p0 = self._sbuf(f"dec{i}.p0s", Cin * 25 * Cout)   # F family (dgrad): [Csmall=Cin][25][Cbig=Cout]
+                fwd.add("vp_pack_w5_split", P(blk.conv.weight), P(p0), P(p1), Cin, Cout)
+                fwd.add("vp_conv5_scatter_bf16x3", P(dec_in_s[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
+                        flops=fl, tag=f"dec{i}.fwd")
+            else:
+                p1 = self._buf(f"dec{i}.p1", Cout * 25 * Cin)
+                p0 = self._buf(f"dec{i}.p0", Cin * 25 * Cout)
+                fwd.add("vp_pack_w5_f32", P(blk.conv.weight), P(p0), P(p1), Cin, Cout)
+                fwd.add("vp_conv5_scatter_f32", P(dec_in[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
+                        flops=fl, tag=f"dec{i}.fwd")
+            nxt16 = i + 1 < L and dec16[i + 1]
+            u = None if nxt16 else self._buf(f"dec{i}.u", n_out)
+            u_s = self._sbuf(f"dec{i}.us", n_out) if nxt16 else None
+            mean, rstd, ws = bn_block(f"dec{i}", tbuf, B * 4 * Hs * Hs, Cout, blk.bn, u, u_s)
             dec_rec.append((blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws))
             dec_in.append(u)
+            dec_in_s.append(u_s)
         fin = dec.conv[L][0]
         Cf = dec_ch[-1]
         fp0 = self._buf("fin.p0", C * 25 * Cf)
@@ -219,14 +269,23 @@ class FusedVAEStep:
         gA, gB = self._buf("g.A", big), self._buf("g.B", big)
         bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         cur, other = gA, gB
+        gS = self._sbuf("g.S", big) if x3 else None     # split gradient (output of BN backward) for the 16-bit kernels
         for i in range(L - 1, -1, -1):
             blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws = dec_rec[i]
             R = B * 4 * Hs * Hs
-            bn_block_bwd(tbuf, cur, other, R, Cout, blk.bn, mean, rstd, ws)          # other = d t_i
-            bwd.add("vp_conv5_wgrad_f32", P(other), P(dec_in[i]), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2,
-                    P(ws_wg), ws_wg.numel() * 4, flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"dec{i}.wgrad")
-            bwd.add("vp_conv5_gather_f32", P(other), P(p0), None, P(cur), B, Hs, Hs, Cout, Cin, 2, _ACT_NONE,
-                    flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"dec{i}.dgrad")  # cur = d input_i
+            fl = 50.0 * B * Hs * Hs * Cin * Cout
+            if dec16[i]:
+                bn_block_bwd(tbuf, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)      # gS = d t_i (split)
+                bwd.add("vp_conv5_wgrad_bf16x3", P(gS), P(dec_in_s[i]), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2,
+                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"dec{i}.wgrad")
+                bwd.add("vp_conv5_gather_bf16x3", P(gS), P(p0), None, P(cur), B, Hs, Hs, Cout, Cin, 2, _ACT_NONE,
+                        flops=fl, tag=f"dec{i}.dgrad")                                     # cur = d input_i
+            else:
+                bn_block_bwd(tbuf, cur, other, R, Cout, blk.bn, mean, rstd, ws)          # other = d t_i
+                bwd.add("vp_conv5_wgrad_f32", P(other), P(dec_in[i]), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2,
+                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"dec{i}.wgrad")
+                bwd.add("vp_conv5_gather_f32", P(other), P(p0), None, P(cur), B, Hs, Hs, Cout, Cin, 2, _ACT_NONE,
+                        flops=fl, tag=f"dec{i}.dgrad")                                     # cur = d input_i
         bwd.add("vp_nhwc_to_nchw_f32", P(cur), P(other), B, dsize, 8, 8)                # other = d db  (B, F1)
         bn_block_bwd(d, other, cur, B, F1, dfc_bn, d_mean, d_rstd, d_ws)                # cur = d d
         ws_g1 = self._ws("g.gemm1.ws", max(lib.vp_gemm_workspace_bytes(F1, Z, B), lib.vp_gemm_workspace_bytes(B, Z, F1),
@@ -250,9 +309,10 @@ class FusedVAEStep:
         bwd = bwd_b
         dh = self._buf("g.dh", B * 1024)
 
-        def bn_block_bwd2(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws):
-            bwd.add("vp_bn_act_bwd_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(dx_buf),
-                    P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1, P(ws), ws.numel() * 4)
+        def bn_block_bwd2(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None):
+            bwd.add("vp_bn_act_bwd_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
+                    P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1,
+                    P(ws), ws.numel() * 4)
 
         bn_block_bwd2(h, dhb_a, dh, B, 1024, fc_bn, h_mean, h_rstd, h_ws)
         bwd.add("vp_gemm_f32", P(dh), 1, 1024, P(flat), 1, F0, P(grad_of(fc_lin.weight)), F0, None, 1024, F0, B, 2, P(ws_g1), wsn)
@@ -262,12 +322,21 @@ class FusedVAEStep:
         for i in range(L - 1, -1, -1):
             blk, Cin, Cout, Hs, p1, c, mean, rstd, ws = enc_rec[i]
             R = B * Hs * Hs
-            bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)               # other = d c_i
-            bwd.add("vp_conv5_wgrad_f32", P(enc_in[i]), P(other), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,
-                    P(ws_wg), ws_wg.numel() * 4, flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"enc{i}.wgrad")
-            if i > 0:
-                bwd.add("vp_conv5_scatter_f32", P(other), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
-                        flops=50.0 * B * Hs * Hs * Cin * Cout, tag=f"enc{i}.dgrad")  # cur = d a_{i-1}
+            fl = 50.0 * B * Hs * Hs * Cin * Cout
+            if enc16[i]:
+                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)        # gS = d c_i (split)
+                bwd.add("vp_conv5_wgrad_bf16x3", P(enc_in_s[i]), P(gS), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,
+                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"enc{i}.wgrad")
+                if i > 0:
+                    bwd.add("vp_conv5_scatter_bf16x3", P(gS), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
+                            flops=fl, tag=f"enc{i}.dgrad")                                 # cur = d a_{i-1}
+            else:
+                bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)            # other = d c_i
+                bwd.add("vp_conv5_wgrad_f32", P(enc_in[i]), P(other), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,
+                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"enc{i}.wgrad")
+                if i > 0:
+                    bwd.add("vp_conv5_scatter_f32", P(other), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
+                            flops=fl, tag=f"enc{i}.dgrad")                                 # cur = d a_{i-1}
         self._fwd, self._bwd_b = fwd, bwd
         self._bn_mods = [m for m in self.vae.modules() if hasattr(m, "num_batches_tracked")]
 

@@ -285,3 +285,65 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step: int, grad_scale: float = 
 
 def rmsprop_step(p, g, sq, lr, alpha, eps, grad_scale: float = 1.0):
     _lib.call("vp_rmsprop_f32", _p(p), _p(g), _p(sq), p.numel(), float(lr), float(alpha), float(eps), float(grad_scale), _stream())
+
+
+# ---- split-bf16 ("bf16x3") operands ----------------------------------------------------------------
+# A split tensor is an int16 tensor of shape (2, n): plane 0 = bf16(x), plane 1 = bf16(x - plane0).
+def _pv(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.VaePlayHipError("vae_play_amd ops need tensors on the HIP device (no CPU path exists)")
+    return c_void_p(t.data_ptr())
+
+
+def empty_split(n: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty((2, n), dtype=torch.int16, device=like.device)
+
+
+def split_f32(x: torch.Tensor) -> torch.Tensor:
+    x = x if x.is_contiguous() or _is_nhwc(x) else x.contiguous()
+    out = empty_split(x.numel(), x)
+    _lib.call("vp_split_f32", _p(x), _pv(out), x.numel(), _stream())
+    return out
+
+
+def unsplit(s: torch.Tensor) -> torch.Tensor:
+    """hi + lo as fp32 (test helper; torch ops)."""
+    return s[0].view(torch.bfloat16).float() + s[1].view(torch.bfloat16).float()
+
+
+def pack_w5_split(w_ref: torch.Tensor, want_p0: bool, want_p1: bool):
+    Cs, Cb = w_ref.shape[0], w_ref.shape[1]
+    w_ref = w_ref.contiguous()
+    n = Cs * Cb * 25
+    p0 = empty_split(n, w_ref) if want_p0 else None
+    p1 = empty_split(n, w_ref) if want_p1 else None
+    _lib.call("vp_pack_w5_split", _p(w_ref), _pv(p0), _pv(p1), Cs, Cb, _stream())
+    return p0, p1
+
+
+def conv5_gather_bf16x3(big_split, shape_big, w_p0_split, Cs: int, bias, stride: int, act: int = ACT_NONE):
+    B, Cb, Hb, Wb = shape_big
+    Hs, Ws = Hb // stride, Wb // stride
+    out = torch.empty((B, Cs, Hs, Ws), dtype=torch.float32, device=big_split.device, memory_format=torch.channels_last)
+    _lib.call("vp_conv5_gather_bf16x3", _pv(big_split), _pv(w_p0_split), _p(bias), _p(out), B, Hs, Ws, Cb, Cs, stride, act, _stream())
+    return out
+
+
+def conv5_scatter_bf16x3(small_split, shape_small, w_p1_split, Cb: int, stride: int):
+    B, Cs, Hs, Ws = shape_small
+    out = torch.empty((B, Cb, Hs * stride, Ws * stride), dtype=torch.float32, device=small_split.device,
+                      memory_format=torch.channels_last)
+    _lib.call("vp_conv5_scatter_bf16x3", _pv(small_split), _pv(w_p1_split), _p(out), B, Hs, Ws, Cs, Cb, stride, _stream())
+    return out
+
+
+def conv5_wgrad_bf16x3(big_split, shape_big, small_split, shape_small, stride: int):
+    B, Cb, Hb, Wb = shape_big
+    _, Cs, Hs, Ws = shape_small
+    nbytes = _lib.load().vp_conv5_wgrad_bf16x3_workspace_bytes(B, Hs, Ws, Cb, Cs, stride)
+    ws = torch.empty(max(4, (nbytes + 3) // 4), dtype=torch.float32, device=big_split.device)
+    dw = torch.empty((Cs, Cb, 5, 5), dtype=torch.float32, device=big_split.device)
+    _lib.call("vp_conv5_wgrad_bf16x3", _pv(big_split), _pv(small_split), _p(dw), B, Hs, Ws, Cb, Cs, stride, _p(ws), ws.numel() * 4, _stream())
+    return dw
