@@ -20,6 +20,7 @@
 //  * accumulator layout and store path identical to igemm.h (lane = output channel).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "problems.h"
 
 namespace vp {
@@ -30,8 +31,10 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
-constexpr int BK16 = 32;              // elements per K-tile
-constexpr int MK_STRIDE_B = 80;       // bytes per MK row: 64 data + 16 pad
+// K-tile depth BKT (elements) is a template parameter: 32 or 64.  MK rows are padded by 16 B
+// (80-B / 144-B stride: every 16-lane ds_read_b128 group covers all 64 banks).
+template <int BKT>
+struct MkStride { static constexpr int bytes = BKT * 2 + 16; };
 
 VP_HD u32x4_t zero_u4() { u32x4_t z = {0u, 0u, 0u, 0u}; return z; }
 VP_HD u32x4_t ld16(const u16* p) {
@@ -47,9 +50,13 @@ template <int BR>
 struct KmStride {
   static constexpr int bytes = (BR == 128) ? 320 : (BR == 64 ? 192 : (BR == 32 ? 64 : -1));
 };
-template <int BR, bool KM>
+// The lo plane starts 64 B past a multiple of 128 B after the hi plane: an 8-lane ds_write_b128 group
+// that stores 4 hi + 4 lo chunks of one row (BKT = 32) then covers 32 distinct banks (it was a 2-way
+// conflict -- 1/3 of all LDS cycles in the first PMC profile -- when both planes started on bank 0).
+template <int BR, bool KM, int BKT>
 struct Lds16 {
-  static constexpr int plane_bytes = KM ? BK16 * KmStride<BR>::bytes : BR * MK_STRIDE_B;
+  static constexpr int raw = KM ? BKT * KmStride<BR>::bytes : BR * MkStride<BKT>::bytes;
+  static constexpr int plane_bytes = ((raw + 127) / 128) * 128 + 64;
 };
 
 // ---- problem descriptors (vector path only: channel counts are multiples of 8) -----------------
@@ -66,23 +73,24 @@ struct ProbF16 {
   VP_HD void z_setup(int, ZCtx& z) const { z.k_begin = 0; z.k_end = K; }
   VP_HD ARow a_row(int m, const ZCtx&) const {
     ARow r; r.valid = m < M; int mm = r.valid ? m : 0;
-    int b = mm / (g.Hs * g.Ws); int rem = mm - b * (g.Hs * g.Ws);
-    int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+    int b = (int)g.dHW.div((uint32_t)mm); int rem = mm - b * (g.Hs * g.Ws);
+    int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
     r.pix_base = b * g.Hb * g.Wb; r.h0 = g.stride * hs - 2; r.w0 = g.stride * ws - 2;
     return r;
   }
+  // every gather is branch-free: the load is always issued (address clamped to element 0 of the plane)
+  // and the result is zero-selected afterwards, so a K-tile's loads are issued back to back
   VP_HD u32x4_t a_load(const ARow& r, int k, int plane, const ZCtx&) const {
-    if (!r.valid || k >= K) return zero_u4();
-    int tap = k / g.Cb, c = k - tap * g.Cb;
-    int rr = tap / 5, qq = tap - rr * 5;
+    int tap = (int)g.dCb.div((uint32_t)k), c = k - tap * g.Cb;
+    int rr = div_small(tap, 5), qq = tap - rr * 5;
     int h = r.h0 + rr, w_ = r.w0 + qq;
-    if (h < 0 || h >= g.Hb || w_ < 0 || w_ >= g.Wb) return zero_u4();
-    return ld16(big + plane * big_plane + (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c);
+    const bool ok = r.valid && k < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+    return ld16(ok ? big + plane * big_plane + (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c : VP_ZERO_U16);
   }
   VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * K; return r; }
   VP_HD u32x4_t b_load(const BRow& r, int k, int plane, const ZCtx&) const {
-    if (!r.valid || k >= K) return zero_u4();
-    return ld16(w + plane * w_plane + (size_t)r.off + k);
+    const bool ok = r.valid && k < K;
+    return ld16(ok ? w + plane * w_plane + (size_t)r.off + k : VP_ZERO_U16);
   }
   VP_HD void store(int m, int n, float v, const ZCtx&) const {
     if (m >= M || n >= N) return;
@@ -108,31 +116,30 @@ struct ProbT16 {
   }
   VP_HD ARow a_row(int m, const ZCtx&) const {
     ARow r; r.valid = m < M; int mm = r.valid ? m : 0;
-    int b = mm / (g.Hs * g.Ws); int rem = mm - b * (g.Hs * g.Ws);
-    r.q = rem / g.Ws; r.p = rem - r.q * g.Ws; r.pix_base = b * g.Hs * g.Ws;
+    int b = (int)g.dHW.div((uint32_t)mm); int rem = mm - b * (g.Hs * g.Ws);
+    r.q = (int)g.dW.div((uint32_t)rem); r.p = rem - r.q * g.Ws; r.pix_base = b * g.Hs * g.Ws;
     return r;
   }
   VP_HD u32x4_t a_load(const ARow& r, int k, int plane, const ZCtx& z) const {
-    if (!r.valid || k >= z.k_end) return zero_u4();
-    int t = k / g.Cs, c = k - t * g.Cs;
-    int rp = t / z.tw, qp = t - rp * z.tw;
-    int d0 = 2 / g.stride;
+    int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
+    int rp = div_small(t, z.tw), qp = t - rp * z.tw;
+    int d0 = g.stride == 2 ? 1 : 2;
     int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
-    if (h < 0 || h >= g.Hs || w_ < 0 || w_ >= g.Ws) return zero_u4();
-    return ld16(small + plane * small_plane + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c);
+    const bool ok = r.valid && k < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
+    return ld16(ok ? small + plane * small_plane + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : VP_ZERO_U16);
   }
   VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * kTaps * g.Cs; return r; }
   VP_HD u32x4_t b_load(const BRow& r, int k, int plane, const ZCtx& z) const {
-    if (!r.valid || k >= z.k_end) return zero_u4();
-    int t = k / g.Cs, c = k - t * g.Cs;
-    int rp = t / z.tw, qp = t - rp * z.tw;
+    int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
+    int rp = div_small(t, z.tw), qp = t - rp * z.tw;
     int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
-    return ld16(w + plane * w_plane + (size_t)r.off + tap * g.Cs + c);
+    const bool ok = r.valid && k < z.k_end;
+    return ld16(ok ? w + plane * w_plane + (size_t)r.off + tap * g.Cs + c : VP_ZERO_U16);
   }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
-    int b = m / (g.Hs * g.Ws); int rem = m - b * (g.Hs * g.Ws);
-    int q = rem / g.Ws, p = rem - q * g.Ws;
+    int b = (int)g.dHW.div((uint32_t)m); int rem = m - b * (g.Hs * g.Ws);
+    int q = (int)g.dW.div((uint32_t)rem), p = rem - q * g.Ws;
     int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
     out[((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n] = v;
   }
@@ -152,16 +159,15 @@ struct ProbW16 {
     int e = z.k_begin + k_per_split; z.k_end = e < K ? e : K;
   }
   VP_HD u32x4_t a_load_km(int k, int m, int plane, const ZCtx& z) const {   // small[pixel k][m..m+7]
-    if (k >= z.k_end || m >= M) return zero_u4();
-    return ld16(small + plane * small_plane + (size_t)k * g.Cs + m);
+    const bool ok = k < z.k_end && m < M;
+    return ld16(ok ? small + plane * small_plane + (size_t)k * g.Cs + m : VP_ZERO_U16);
   }
   VP_HD u32x4_t b_load_km(int k, int n, int plane, const ZCtx& z) const {   // big[shifted pixel][n..n+7]
-    if (k >= z.k_end || n >= N) return zero_u4();
-    int b = k / (g.Hs * g.Ws); int rem = k - b * (g.Hs * g.Ws);
-    int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+    int b = (int)g.dHW.div((uint32_t)k); int rem = k - b * (g.Hs * g.Ws);
+    int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
     int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
-    if (h < 0 || h >= g.Hb || w_ < 0 || w_ >= g.Wb) return zero_u4();
-    return ld16(big + plane * big_plane + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb + n);
+    const bool ok = k < z.k_end && n < N && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+    return ld16(ok ? big + plane * big_plane + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb + n : VP_ZERO_U16);
   }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
@@ -179,10 +185,10 @@ template <class P, int NR> struct Rows16B<P, NR, false> { typename P::BRow r[NR]
 template <class P, int NR> struct Rows16B<P, NR, true> {};
 
 // fragment fetch: 8 bf16 (k = 8*lh .. 8*lh+7 of MFMA step s) of tile row/column `row`
-template <int BR, bool KM>
+template <int BR, bool KM, int BKT>
 __device__ __forceinline__ bf16x8_t frag16(const unsigned char* plane, int row, int s, int li, int lh, int lane) {
   if constexpr (!KM) {
-    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(plane + row * MK_STRIDE_B + s * 32 + lh * 16);
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(plane + row * MkStride<BKT>::bytes + s * 32 + lh * 16);
     return __builtin_bit_cast(bf16x8_t, v);
   } else {
     // transposing read: within a 16-lane group, lane i supplies &T[k0 + (i>>2)][col0 + 4*(i&3)] and
@@ -199,14 +205,18 @@ __device__ __forceinline__ bf16x8_t frag16(const unsigned char* plane, int row, 
   }
 }
 
-template <class P, int BM, int BN, int WM, int WN>
+template <class P, int BM, int BN, int WM, int WN, int BKT>
 __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(BKT == 32 || BKT == 64, "K-tile depth");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
-  constexpr int NA = BM / 32, NB = BN / 32;   // 16-B chunks per thread per K-tile (both planes)
-  constexpr int A_PLANE = Lds16<BM, P::A_KM>::plane_bytes;
-  constexpr int B_PLANE = Lds16<BN, P::B_KM>::plane_bytes;
+  constexpr int KC = BKT / 8;                 // 16-B chunks per row and plane
+  constexpr int NA = BM * KC / 128, NB = BN * KC / 128;   // 16-B chunks per thread per K-tile (both planes)
+  constexpr int A_PLANE = Lds16<BM, P::A_KM, BKT>::plane_bytes;
+  constexpr int B_PLANE = Lds16<BN, P::B_KM, BKT>::plane_bytes;
+  constexpr int MKS = MkStride<BKT>::bytes;
+  constexpr int RPP = 256 / (2 * KC);         // MK rows staged per pass
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_PLANE + 2 * B_PLANE];
   unsigned char* As = lds;                   // [plane][...]
   unsigned char* Bs = lds + 2 * A_PLANE;
@@ -220,23 +230,23 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   typename P::ZCtx z;
   p.z_setup(blockIdx.z, z);
 
-  // staging map.  MK: chunk = (row = tid/8 + 32*i, sub = tid%8 -> plane = sub/4, k8 = sub%4)
+  // staging map.  MK: chunk = (row = tid/(2*KC) + RPP*i, sub = tid%(2*KC) -> plane = sub/KC, k8 = sub%KC)
   //               KM: chunk = (krow, col8, plane) with V = BR/8 chunks per k-row and plane
   Rows16A<P, NA, P::A_KM> ra;
   Rows16B<P, NB, P::B_KM> rb;
   if constexpr (!P::A_KM) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra.r[i] = p.a_row(m0 + (tid >> 3) + 32 * i, z);
+    for (int i = 0; i < NA; ++i) ra.r[i] = p.a_row(m0 + tid / (2 * KC) + RPP * i, z);
   }
   if constexpr (!P::B_KM) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb.r[i] = p.b_row(n0 + (tid >> 3) + 32 * i, z);
+    for (int i = 0; i < NB; ++i) rb.r[i] = p.b_row(n0 + tid / (2 * KC) + RPP * i, z);
   }
   u32x4_t sa[NA], sb[NB];
 
   auto stage_load = [&](int k0) {
     if constexpr (!P::A_KM) {
-      const int plane = (tid & 7) >> 2, k8 = (tid & 3) * 8;
+      const int plane = (tid % (2 * KC)) / KC, k8 = (tid % KC) * 8;
 #pragma unroll
       for (int i = 0; i < NA; ++i) sa[i] = p.a_load(ra.r[i], k0 + k8, plane, z);
     } else {
@@ -250,7 +260,7 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       }
     }
     if constexpr (!P::B_KM) {
-      const int plane = (tid & 7) >> 2, k8 = (tid & 3) * 8;
+      const int plane = (tid % (2 * KC)) / KC, k8 = (tid % KC) * 8;
 #pragma unroll
       for (int i = 0; i < NB; ++i) sb[i] = p.b_load(rb.r[i], k0 + k8, plane, z);
     } else {
@@ -264,10 +274,10 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   };
   auto stage_write = [&]() {
     if constexpr (!P::A_KM) {
-      const int plane = (tid & 7) >> 2, k8 = (tid & 3);
+      const int plane = (tid % (2 * KC)) / KC, k8 = tid % KC;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        *reinterpret_cast<u32x4_t*>(As + plane * A_PLANE + ((tid >> 3) + 32 * i) * MK_STRIDE_B + k8 * 16) = sa[i];
+        *reinterpret_cast<u32x4_t*>(As + plane * A_PLANE + (tid / (2 * KC) + RPP * i) * MKS + k8 * 16) = sa[i];
     } else {
       constexpr int V = BM / 8, PER = 2 * V, RP = 256 / PER, S = KmStride<BM>::bytes;
 #pragma unroll
@@ -277,10 +287,10 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       }
     }
     if constexpr (!P::B_KM) {
-      const int plane = (tid & 7) >> 2, k8 = (tid & 3);
+      const int plane = (tid % (2 * KC)) / KC, k8 = tid % KC;
 #pragma unroll
       for (int i = 0; i < NB; ++i)
-        *reinterpret_cast<u32x4_t*>(Bs + plane * B_PLANE + ((tid >> 3) + 32 * i) * MK_STRIDE_B + k8 * 16) = sb[i];
+        *reinterpret_cast<u32x4_t*>(Bs + plane * B_PLANE + (tid / (2 * KC) + RPP * i) * MKS + k8 * 16) = sb[i];
     } else {
       constexpr int V = BN / 8, PER = 2 * V, RP = 256 / PER, S = KmStride<BN>::bytes;
 #pragma unroll
@@ -300,7 +310,7 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int klen = z.k_end - z.k_begin;
-  const int nk = klen > 0 ? (klen + BK16 - 1) / BK16 : 0;
+  const int nk = klen > 0 ? (klen + BKT - 1) / BKT : 0;
   const int arow0 = wm * (BM / WM) + li;
   const int brow0 = wn * (BN / WN) + li;
 
@@ -311,19 +321,19 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   }
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) stage_load(z.k_begin + (kt + 1) * BK16);
+    if (more) stage_load(z.k_begin + (kt + 1) * BKT);
 #pragma unroll
-    for (int s = 0; s < BK16 / 16; ++s) {
+    for (int s = 0; s < BKT / 16; ++s) {
       bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = frag16<BM, P::A_KM>(As, arow0 + 32 * i, s, li, lh, lane);
-        al[i] = frag16<BM, P::A_KM>(As + A_PLANE, arow0 + 32 * i, s, li, lh, lane);
+        ah[i] = frag16<BM, P::A_KM, BKT>(As, arow0 + 32 * i, s, li, lh, lane);
+        al[i] = frag16<BM, P::A_KM, BKT>(As + A_PLANE, arow0 + 32 * i, s, li, lh, lane);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = frag16<BN, P::B_KM>(Bs, brow0 + 32 * j, s, li, lh, lane);
-        bl[j] = frag16<BN, P::B_KM>(Bs + B_PLANE, brow0 + 32 * j, s, li, lh, lane);
+        bh[j] = frag16<BN, P::B_KM, BKT>(Bs, brow0 + 32 * j, s, li, lh, lane);
+        bl[j] = frag16<BN, P::B_KM, BKT>(Bs + B_PLANE, brow0 + 32 * j, s, li, lh, lane);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -362,18 +372,33 @@ inline Tile16 choose_tile16(long M, long N, int gz) {
   return {64, 64};
 }
 
-template <class P>
-inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t stream) {
+// K-tile depth: 64 for the gather/scatter families (half the barriers per MFMA), 32 for the weight
+// gradient (its [pixel][channel] LDS images at depth 64 leave one workgroup per CU).  Measured on
+// MI355X, profiles/; VP_IGEMM16_BK=32|64 overrides both for A/B runs.
+inline int igemm16_bk(bool km) {
+  static int forced = [] { const char* e = getenv("VP_IGEMM16_BK"); return e ? atoi(e) : 0; }();
+  if (forced == 32 || forced == 64) return forced;
+  return km ? 32 : 64;
+}
+
+template <class P, int BKT>
+inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t stream) {
   Tile16 t = choose_tile16(M, N, gz);
   dim3 block(256);
   auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
   if (t.bm == 128 && t.bn == 128) {
-    hipLaunchKernelGGL((igemm16_kernel<P, 128, 128, 2, 2>), grid(128, 128), block, 0, stream, p);
+    hipLaunchKernelGGL((igemm16_kernel<P, 128, 128, 2, 2, BKT>), grid(128, 128), block, 0, stream, p);
   } else if (t.bm == 128 && t.bn == 64) {
-    hipLaunchKernelGGL((igemm16_kernel<P, 128, 64, 2, 2>), grid(128, 64), block, 0, stream, p);
+    hipLaunchKernelGGL((igemm16_kernel<P, 128, 64, 2, 2, BKT>), grid(128, 64), block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((igemm16_kernel<P, 64, 64, 2, 2>), grid(64, 64), block, 0, stream, p);
+    hipLaunchKernelGGL((igemm16_kernel<P, 64, 64, 2, 2, BKT>), grid(64, 64), block, 0, stream, p);
   }
+}
+
+template <class P>
+inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t stream) {
+  if (igemm16_bk(P::A_KM) == 32) launch_igemm16_bk<P, 32>(p, M, N, gz, stream);
+  else launch_igemm16_bk<P, 64>(p, M, N, gz, stream);
 }
 #endif  // __HIPCC__
 

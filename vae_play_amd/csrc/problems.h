@@ -17,6 +17,7 @@
 // Reference: models/networks.py:14 (Conv2d k5 s2 p2), :38 (ConvTranspose2d k5 s2 p2 op1),
 //            :100-103 (Conv2d k5 s1 p2 + bias + Sigmoid).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__) || defined(__HIP__)
@@ -35,6 +36,21 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3, ACT_SI
 
 VP_HD vp_f32x4 zero4() { vp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
+// Zero page: out-of-range gathers (padding taps, rows past M, k past K) load these 16 zero bytes
+// instead of being predicated or zero-selected after the load.  A select right after the load makes
+// the compiler wait for the prefetch *before* the MFMAs of the current tile (measured: the K-loop
+// then pays the full memory latency every tile); with the zero page the first use of the loaded
+// registers is the LDS write after the MFMAs.
+#if defined(__HIPCC__) || defined(__HIP__)
+__device__ __attribute__((aligned(16))) const unsigned int vp_zero_page[4] = {0u, 0u, 0u, 0u};
+#define VP_ZERO_F32 (reinterpret_cast<const float*>(vp_zero_page))
+#define VP_ZERO_U16 (reinterpret_cast<const unsigned short*>(vp_zero_page))
+#else
+static const unsigned int vp_zero_page_host[4] = {0u, 0u, 0u, 0u};
+#define VP_ZERO_F32 (reinterpret_cast<const float*>(vp_zero_page_host))
+#define VP_ZERO_U16 (reinterpret_cast<const unsigned short*>(vp_zero_page_host))
+#endif
+
 // 16-byte load.  Callers guarantee 16-B alignment whenever they take the vector path (the
 // host sets the vec flags from strides/channel counts), so the device gets one dwordx4 load.
 VP_HD vp_f32x4 ld4(const float* p) {
@@ -47,8 +63,48 @@ VP_HD vp_f32x4 ld4(const float* p) {
 #endif
 }
 
+// Division by a loop-invariant divisor (Granlund-Montgomery): q = (t + ((n - t) >> sh1)) >> sh2 with
+// t = mulhi(m, n).  gfx950 has no integer divider (a runtime `/` is ~40 VALU instructions); the
+// loaders decompose k -> (tap, channel) and pixel -> (b, h, w) for every 16-byte gather, which cost
+// more VALU issue time than the bf16 MFMAs of a K-tile before this was introduced.
+struct FastDiv {
+  uint32_t d, m, sh1, sh2;
+  VP_HD uint32_t div(uint32_t n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(m, n);
+#else
+    const uint32_t t = (uint32_t)(((uint64_t)m * n) >> 32);
+#endif
+    return (t + ((n - t) >> sh1)) >> sh2;
+  }
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t L = 0;
+  while ((1ull << L) < d) ++L;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+  f.sh1 = L < 1 ? L : 1;
+  f.sh2 = L > 0 ? L - 1 : 0;
+  return f;
+}
+
+// t / tw for the tap-column counts that occur (1..5): branch-free select of constant-divisor results
+VP_HD int div_small(int t, int tw) {
+  const int q3 = (int)(((unsigned)t * 43691u) >> 17);    // t / 3 for t < 98304
+  const int q5 = (int)(((unsigned)t * 52429u) >> 18);    // t / 5 for t < 81920
+  int q = t;
+  q = tw == 2 ? (t >> 1) : q;
+  q = tw == 3 ? q3 : q;
+  q = tw == 4 ? (t >> 2) : q;
+  q = tw == 5 ? q5 : q;
+  return q;
+}
+
 struct ConvGeom {
   int B, Hs, Ws, Hb, Wb, Cs, Cb, stride;
+  FastDiv dHW, dW, dCs, dCb;   // divisors Hs*Ws, Ws, Cs, Cb
 };
 
 // --------------------------------------------------------------------------------------------
@@ -76,9 +132,9 @@ struct ProbF {
     ARow r;
     r.valid = m < M;
     int mm = r.valid ? m : 0;
-    int b = mm / (g.Hs * g.Ws);
+    int b = (int)g.dHW.div((uint32_t)mm);
     int rem = mm - b * (g.Hs * g.Ws);
-    int hs = rem / g.Ws;
+    int hs = (int)g.dW.div((uint32_t)rem);
     int ws = rem - hs * g.Ws;
     r.pix_base = b * g.Hb * g.Wb;
     r.h0 = g.stride * hs - 2;
@@ -87,20 +143,19 @@ struct ProbF {
   }
   VP_HD float a_elem(const ARow& r, int k) const {
     if (!r.valid || k >= K) return 0.f;
-    int tap = k / g.Cb, c = k - tap * g.Cb;
+    int tap = (int)g.dCb.div((uint32_t)k), c = k - tap * g.Cb;
     int rr = tap / 5, qq = tap - rr * 5;
     int h = r.h0 + rr, w = r.w0 + qq;
     if (h < 0 || h >= g.Hb || w < 0 || w >= g.Wb) return 0.f;
     return big[(size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c];
   }
   VP_HD vp_f32x4 a_load(const ARow& r, int k, const ZCtx&) const {
-    if (vec) {
-      if (!r.valid || k >= K) return zero4();
-      int tap = k / g.Cb, c = k - tap * g.Cb;
-      int rr = tap / 5, qq = tap - rr * 5;
+    if (vec) {   // branch-free: always load (address clamped to element 0), then select
+      int tap = (int)g.dCb.div((uint32_t)k), c = k - tap * g.Cb;
+      int rr = div_small(tap, 5), qq = tap - rr * 5;
       int h = r.h0 + rr, w = r.w0 + qq;
-      if (h < 0 || h >= g.Hb || w < 0 || w >= g.Wb) return zero4();
-      return ld4(big + (size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c);
+      const bool ok = r.valid && k < K && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
+      return ld4(ok ? big + (size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c : VP_ZERO_F32);
     }
     vp_f32x4 v = {a_elem(r, k), a_elem(r, k + 1), a_elem(r, k + 2), a_elem(r, k + 3)};
     return v;
@@ -112,8 +167,11 @@ struct ProbF {
     return r;
   }
   VP_HD vp_f32x4 b_load(const BRow& r, int k, const ZCtx&) const {
+    if (vec) {
+      const bool ok = r.valid && k + 3 < K;
+      return ld4(ok ? w + (size_t)r.off + k : VP_ZERO_F32);
+    }
     if (!r.valid) return zero4();
-    if (vec && k + 3 < K) return ld4(w + (size_t)r.off + k);
     vp_f32x4 v = zero4();
     for (int j = 0; j < 4; ++j)
       if (k + j < K) v[j] = w[(size_t)r.off + k + j];
@@ -158,31 +216,30 @@ struct ProbT {
     ARow r;
     r.valid = m < M;
     int mm = r.valid ? m : 0;
-    int b = mm / (g.Hs * g.Ws);
+    int b = (int)g.dHW.div((uint32_t)mm);
     int rem = mm - b * (g.Hs * g.Ws);
-    r.q = rem / g.Ws;
+    r.q = (int)g.dW.div((uint32_t)rem);
     r.p = rem - r.q * g.Ws;
     r.pix_base = b * g.Hs * g.Ws;
     return r;
   }
   VP_HD float a_elem(const ARow& r, int k, const ZCtx& z) const {
     if (!r.valid || k >= z.k_end) return 0.f;
-    int t = k / g.Cs, c = k - t * g.Cs;
-    int rp = t / z.tw, qp = t - rp * z.tw;
-    int d0 = 2 / g.stride;
+    int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
+    int rp = div_small(t, z.tw), qp = t - rp * z.tw;
+    int d0 = g.stride == 2 ? 1 : 2;
     int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
     if (h < 0 || h >= g.Hs || w_ < 0 || w_ >= g.Ws) return 0.f;
     return small[(size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c];
   }
   VP_HD vp_f32x4 a_load(const ARow& r, int k, const ZCtx& z) const {
     if (vec) {
-      if (!r.valid || k >= z.k_end) return zero4();
-      int t = k / g.Cs, c = k - t * g.Cs;
-      int rp = t / z.tw, qp = t - rp * z.tw;
-      int d0 = 2 / g.stride;
+      int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
+      int rp = div_small(t, z.tw), qp = t - rp * z.tw;
+      int d0 = g.stride == 2 ? 1 : 2;
       int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
-      if (h < 0 || h >= g.Hs || w_ < 0 || w_ >= g.Ws) return zero4();
-      return ld4(small + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c);
+      const bool ok = r.valid && k < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
+      return ld4(ok ? small + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : VP_ZERO_F32);
     }
     vp_f32x4 v = {a_elem(r, k, z), a_elem(r, k + 1, z), a_elem(r, k + 2, z), a_elem(r, k + 3, z)};
     return v;
@@ -195,27 +252,27 @@ struct ProbT {
   }
   VP_HD float b_elem(const BRow& r, int k, const ZCtx& z) const {
     if (!r.valid || k >= z.k_end) return 0.f;
-    int t = k / g.Cs, c = k - t * g.Cs;
-    int rp = t / z.tw, qp = t - rp * z.tw;
+    int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
+    int rp = div_small(t, z.tw), qp = t - rp * z.tw;
     int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
     return w[(size_t)r.off + tap * g.Cs + c];
   }
   VP_HD vp_f32x4 b_load(const BRow& r, int k, const ZCtx& z) const {
     if (vec) {
-      if (!r.valid || k >= z.k_end) return zero4();
-      int t = k / g.Cs, c = k - t * g.Cs;
-      int rp = t / z.tw, qp = t - rp * z.tw;
+      int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
+      int rp = div_small(t, z.tw), qp = t - rp * z.tw;
       int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
-      return ld4(w + (size_t)r.off + tap * g.Cs + c);
+      const bool ok = r.valid && k < z.k_end;
+      return ld4(ok ? w + (size_t)r.off + tap * g.Cs + c : VP_ZERO_F32);
     }
     vp_f32x4 v = {b_elem(r, k, z), b_elem(r, k + 1, z), b_elem(r, k + 2, z), b_elem(r, k + 3, z)};
     return v;
   }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
-    int b = m / (g.Hs * g.Ws);
+    int b = (int)g.dHW.div((uint32_t)m);
     int rem = m - b * (g.Hs * g.Ws);
-    int q = rem / g.Ws, p = rem - q * g.Ws;
+    int q = (int)g.dW.div((uint32_t)rem), p = rem - q * g.Ws;
     int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
     out[((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n] = v;
   }
@@ -260,9 +317,9 @@ struct ProbW {
   // B(k = pixel, n .. n+3) = big[b, s*hs-2+r, s*ws-2+q][n..n+3]
   VP_HD vp_f32x4 b_load_km(int k, int n, const ZCtx& z) const {
     if (k >= z.k_end) return zero4();
-    int b = k / (g.Hs * g.Ws);
+    int b = (int)g.dHW.div((uint32_t)k);
     int rem = k - b * (g.Hs * g.Ws);
-    int hs = rem / g.Ws, ws = rem - hs * g.Ws;
+    int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
     int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
     if (h < 0 || h >= g.Hb || w_ < 0 || w_ >= g.Wb) return zero4();
     const float* p = big + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb;
@@ -368,6 +425,8 @@ inline ConvGeom make_geom(int B, int Hs, int Ws, int Cs, int Cb, int stride) {
   ConvGeom g;
   g.B = B; g.Hs = Hs; g.Ws = Ws; g.Hb = Hs * stride; g.Wb = Ws * stride;
   g.Cs = Cs; g.Cb = Cb; g.stride = stride;
+  g.dHW = make_fastdiv((uint32_t)(Hs * Ws)); g.dW = make_fastdiv((uint32_t)Ws);
+  g.dCs = make_fastdiv((uint32_t)Cs); g.dCb = make_fastdiv((uint32_t)Cb);
   return g;
 }
 
