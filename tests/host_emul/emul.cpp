@@ -13,6 +13,11 @@
 
 using namespace vp;
 
+namespace vp {
+static const unsigned int host_zero_page[16] = {0};
+const void* vp_zero_page() { return host_zero_page; }
+}
+
 template <class P>
 static void emulate(const P& p, int M, int N, int gz) {
   for (int zi = 0; zi < gz; ++zi) {

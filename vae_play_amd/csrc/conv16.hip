@@ -94,6 +94,7 @@ int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const 
   VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_gather_bf16x3: stride must be 1 or 2");
   VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv5_gather_bf16x3: epilogue supports none|sigmoid");
   ProbF16 p;
+  p.zero = vp_zero_page();
   p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
   p.big = (const u16*)big_split; p.big_plane = (size_t)B * p.g.Hb * p.g.Wb * Cbig;
   p.w = (const u16*)w_p0_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
@@ -109,6 +110,7 @@ int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, flo
   VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Csmall % 8 == 0, "vp_conv5_scatter_bf16x3: Csmall must be a multiple of 8");
   VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_scatter_bf16x3: stride must be 1 or 2");
   ProbT16 p;
+  p.zero = vp_zero_page();
   p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
   p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
   p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
@@ -132,6 +134,7 @@ int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float*
   const int ns = wgrad_nsplit(g);
   if (ws_bytes < wgrad_slab_floats(g, ns) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_wgrad_bf16x3: workspace too small");
   ProbW16 p;
+  p.zero = vp_zero_page();
   p.g = g;
   p.big = (const u16*)big_split; p.big_plane = (size_t)B * g.Hb * g.Wb * Cbig;
   p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;

@@ -6,6 +6,19 @@
 
 namespace vp {
 
+// 64 zero bytes in global memory: the "zero page" that out-of-range gathers of the implicit-GEMM kernels
+// read (problems.h).  A __device__ symbol of this code object, not an allocation.
+__device__ __attribute__((aligned(64))) unsigned int vp_zero_page_storage[16] = {0};
+
+const void* vp_zero_page() {
+  static const void* ptr = [] {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(vp_zero_page_storage)) != hipSuccess) p = nullptr;
+    return (const void*)p;
+  }();
+  return ptr;
+}
+
 // out[b][c][r] = in[b][r][c]  (32x32 LDS tile, +1 pad: conflict-free for ds_read_b32 columns)
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
                                  u16_t* __restrict__ out_split, size_t plane) {

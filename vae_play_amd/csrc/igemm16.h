@@ -65,7 +65,7 @@ struct ProbF16 {
   static constexpr bool A_KM = false, B_KM = false;
   const u16* big; size_t big_plane;     // hi plane at big, lo plane at big + big_plane (elements)
   const u16* w; size_t w_plane;         // packed P0 planes [Cs][25][Cb]
-  const float* bias; float* out;
+  const float* bias; float* out; const void* zero;
   ConvGeom g; int act; int M, N, K;
   struct ZCtx { int k_begin, k_end; };
   struct ARow { int pix_base, h0, w0, valid; };
@@ -85,12 +85,12 @@ struct ProbF16 {
     int rr = div_small(tap, 5), qq = tap - rr * 5;
     int h = r.h0 + rr, w_ = r.w0 + qq;
     const bool ok = r.valid && k < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
-    return ld16(ok ? big + plane * big_plane + (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c : VP_ZERO_U16);
+    return ld16(ok ? big + plane * big_plane + (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c : reinterpret_cast<const u16*>(zero));
   }
   VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * K; return r; }
   VP_HD u32x4_t b_load(const BRow& r, int k, int plane, const ZCtx&) const {
     const bool ok = r.valid && k < K;
-    return ld16(ok ? w + plane * w_plane + (size_t)r.off + k : VP_ZERO_U16);
+    return ld16(ok ? w + plane * w_plane + (size_t)r.off + k : reinterpret_cast<const u16*>(zero));
   }
   VP_HD void store(int m, int n, float v, const ZCtx&) const {
     if (m >= M || n >= N) return;
@@ -105,7 +105,7 @@ struct ProbT16 {
   static constexpr bool A_KM = false, B_KM = false;
   const u16* small; size_t small_plane;
   const u16* w; size_t w_plane;          // packed P1 planes [Cb][25][Cs]
-  float* out; ConvGeom g; int M, N;
+  float* out; const void* zero; ConvGeom g; int M, N;
   struct ZCtx { int k_begin, k_end, ph, pw, th, tw; };
   struct ARow { int pix_base, q, p, valid; };
   struct BRow { int off, valid; };
@@ -126,7 +126,7 @@ struct ProbT16 {
     int d0 = g.stride == 2 ? 1 : 2;
     int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
     const bool ok = r.valid && k < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
-    return ld16(ok ? small + plane * small_plane + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : VP_ZERO_U16);
+    return ld16(ok ? small + plane * small_plane + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : reinterpret_cast<const u16*>(zero));
   }
   VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * kTaps * g.Cs; return r; }
   VP_HD u32x4_t b_load(const BRow& r, int k, int plane, const ZCtx& z) const {
@@ -134,7 +134,7 @@ struct ProbT16 {
     int rp = div_small(t, z.tw), qp = t - rp * z.tw;
     int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
     const bool ok = r.valid && k < z.k_end;
-    return ld16(ok ? w + plane * w_plane + (size_t)r.off + tap * g.Cs + c : VP_ZERO_U16);
+    return ld16(ok ? w + plane * w_plane + (size_t)r.off + tap * g.Cs + c : reinterpret_cast<const u16*>(zero));
   }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
@@ -150,7 +150,7 @@ struct ProbW16 {
   static constexpr bool A_KM = true, B_KM = true;
   const u16* big; size_t big_plane;
   const u16* small; size_t small_plane;
-  float* slab; ConvGeom g; int M, N, K; int nsplit, k_per_split;
+  float* slab; const void* zero; ConvGeom g; int M, N, K; int nsplit, k_per_split;
   struct ZCtx { int k_begin, k_end, rr, qq, tap, split; };
   VP_HD void z_setup(int zi, ZCtx& z) const {
     z.tap = zi / nsplit; z.split = zi - z.tap * nsplit;
@@ -160,14 +160,14 @@ struct ProbW16 {
   }
   VP_HD u32x4_t a_load_km(int k, int m, int plane, const ZCtx& z) const {   // small[pixel k][m..m+7]
     const bool ok = k < z.k_end && m < M;
-    return ld16(ok ? small + plane * small_plane + (size_t)k * g.Cs + m : VP_ZERO_U16);
+    return ld16(ok ? small + plane * small_plane + (size_t)k * g.Cs + m : reinterpret_cast<const u16*>(zero));
   }
   VP_HD u32x4_t b_load_km(int k, int n, int plane, const ZCtx& z) const {   // big[shifted pixel][n..n+7]
     int b = (int)g.dHW.div((uint32_t)k); int rem = k - b * (g.Hs * g.Ws);
     int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
     int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
     const bool ok = k < z.k_end && n < N && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
-    return ld16(ok ? big + plane * big_plane + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb + n : VP_ZERO_U16);
+    return ld16(ok ? big + plane * big_plane + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb + n : reinterpret_cast<const u16*>(zero));
   }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;

@@ -36,21 +36,13 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3, ACT_SI
 
 VP_HD vp_f32x4 zero4() { vp_f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
-// Zero page: out-of-range gathers (padding taps, rows past M, k past K) load these 16 zero bytes
-// instead of being predicated or zero-selected after the load.  A select right after the load makes
-// the compiler wait for the prefetch *before* the MFMAs of the current tile (measured: the K-loop
-// then pays the full memory latency every tile); with the zero page the first use of the loaded
-// registers is the LDS write after the MFMAs.
-#if defined(__HIPCC__) || defined(__HIP__)
-__device__ __attribute__((aligned(16))) const unsigned int vp_zero_page[4] = {0u, 0u, 0u, 0u};
-#define VP_ZERO_F32 (reinterpret_cast<const float*>(vp_zero_page))
-#define VP_ZERO_U16 (reinterpret_cast<const unsigned short*>(vp_zero_page))
-#else
-static const unsigned int vp_zero_page_host[4] = {0u, 0u, 0u, 0u};
-#define VP_ZERO_F32 (reinterpret_cast<const float*>(vp_zero_page_host))
-#define VP_ZERO_U16 (reinterpret_cast<const unsigned short*>(vp_zero_page_host))
-#endif
-
+// Zero page: out-of-range gathers (padding taps, rows past M, k past K) load 16 zero bytes from a small
+// GLOBAL buffer (`zero` member of every descriptor, see vp_zero_page()) instead of being predicated or
+// zero-selected after the load.  A select right after the load makes the compiler wait for the prefetch
+// *before* the MFMAs of the current tile (the K-loop then pays the full memory latency every tile); with
+// the zero page the first use of the loaded registers is the LDS write after the MFMAs.  The pointer
+// must be a plain global pointer: selecting against a constant-address-space symbol turns the gathers
+// into flat_load, whose lgkmcnt accounting stalls every LDS wait behind the prefetch.
 // 16-byte load.  Callers guarantee 16-B alignment whenever they take the vector path (the
 // host sets the vec flags from strides/channel counts), so the device gets one dwordx4 load.
 VP_HD vp_f32x4 ld4(const float* p) {
@@ -117,6 +109,7 @@ struct ProbF {
   const float* w;     // packed P0: [Cs][25][Cb]
   const float* bias;  // nullable
   float* out;         // [B,Hs,Ws,Cs]
+  const void* zero;   // >= 16 zero bytes in global memory
   ConvGeom g;
   int act;
   int M, N, K;
@@ -155,7 +148,7 @@ struct ProbF {
       int rr = div_small(tap, 5), qq = tap - rr * 5;
       int h = r.h0 + rr, w = r.w0 + qq;
       const bool ok = r.valid && k < K && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
-      return ld4(ok ? big + (size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c : VP_ZERO_F32);
+      return ld4(ok ? big + (size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c : reinterpret_cast<const float*>(zero));
     }
     vp_f32x4 v = {a_elem(r, k), a_elem(r, k + 1), a_elem(r, k + 2), a_elem(r, k + 3)};
     return v;
@@ -169,7 +162,7 @@ struct ProbF {
   VP_HD vp_f32x4 b_load(const BRow& r, int k, const ZCtx&) const {
     if (vec) {
       const bool ok = r.valid && k + 3 < K;
-      return ld4(ok ? w + (size_t)r.off + k : VP_ZERO_F32);
+      return ld4(ok ? w + (size_t)r.off + k : reinterpret_cast<const float*>(zero));
     }
     if (!r.valid) return zero4();
     vp_f32x4 v = zero4();
@@ -195,6 +188,7 @@ struct ProbT {
   const float* small;
   const float* w;  // packed P1: [Cb][25][Cs]
   float* out;      // [B,Hb,Wb,Cb]
+  const void* zero;
   ConvGeom g;
   int M, N;
   int vec;  // Cs % 4 == 0
@@ -239,7 +233,7 @@ struct ProbT {
       int d0 = g.stride == 2 ? 1 : 2;
       int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
       const bool ok = r.valid && k < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
-      return ld4(ok ? small + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : VP_ZERO_F32);
+      return ld4(ok ? small + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : reinterpret_cast<const float*>(zero));
     }
     vp_f32x4 v = {a_elem(r, k, z), a_elem(r, k + 1, z), a_elem(r, k + 2, z), a_elem(r, k + 3, z)};
     return v;
@@ -263,7 +257,7 @@ struct ProbT {
       int rp = div_small(t, z.tw), qp = t - rp * z.tw;
       int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
       const bool ok = r.valid && k < z.k_end;
-      return ld4(ok ? w + (size_t)r.off + tap * g.Cs + c : VP_ZERO_F32);
+      return ld4(ok ? w + (size_t)r.off + tap * g.Cs + c : reinterpret_cast<const float*>(zero));
     }
     vp_f32x4 v = {b_elem(r, k, z), b_elem(r, k + 1, z), b_elem(r, k + 2, z), b_elem(r, k + 3, z)};
     return v;
@@ -430,8 +424,11 @@ inline ConvGeom make_geom(int B, int Hs, int Ws, int Cs, int Cb, int stride) {
   return g;
 }
 
+const void* vp_zero_page();   // device build: elementwise.hip; host emulation: tests/host_emul/emul.cpp
+
 inline ProbF make_probF(const float* big, const float* wp0, const float* bias, float* out, const ConvGeom& g, int act) {
   ProbF p;
+  p.zero = vp_zero_page();
   p.big = big; p.w = wp0; p.bias = bias; p.out = out; p.g = g; p.act = act;
   p.M = g.B * g.Hs * g.Ws; p.N = g.Cs; p.K = kTaps * g.Cb;
   p.vec = (g.Cb % 4 == 0);
@@ -440,6 +437,7 @@ inline ProbF make_probF(const float* big, const float* wp0, const float* bias, f
 
 inline ProbT make_probT(const float* small, const float* wp1, float* out, const ConvGeom& g) {
   ProbT p;
+  p.zero = vp_zero_page();
   p.small = small; p.w = wp1; p.out = out; p.g = g;
   p.M = g.B * g.Hs * g.Ws; p.N = g.Cb;
   p.vec = (g.Cs % 4 == 0);
