@@ -250,13 +250,14 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) sa[i] = p.a_load(ra.r[i], k0 + k8, plane, z);
     } else {
-      constexpr int V = BM / 8;                 // chunks per k-row per plane
-      constexpr int PER = 2 * V;                // chunks per k-row (both planes)
-      constexpr int RP = 256 / PER;             // k-rows per pass
+      // one pixel (k-row) per thread and K-tile: TP threads share a pixel and each stages NA of its
+      // 16-B chunks, so the pixel -> (b, h, w) decomposition is done once, not once per chunk
+      constexpr int V = BM / 8, TP = 256 / BKT;
+      const int kr = tid / TP, c0 = tid % TP;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int kr = tid / PER + RP * i, sub = tid % PER;
-        sa[i] = p.a_load_km(k0 + kr, m0 + (sub % V) * 8, sub / V, z);
+        const int ch = c0 + TP * i;             // chunk index inside the pixel: [plane][V]
+        sa[i] = p.a_load_km(k0 + kr, m0 + (ch % V) * 8, ch / V, z);
       }
     }
     if constexpr (!P::B_KM) {
@@ -264,11 +265,12 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) sb[i] = p.b_load(rb.r[i], k0 + k8, plane, z);
     } else {
-      constexpr int V = BN / 8, PER = 2 * V, RP = 256 / PER;
+      constexpr int V = BN / 8, TP = 256 / BKT;
+      const int kr = tid / TP, c0 = tid % TP;
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int kr = tid / PER + RP * i, sub = tid % PER;
-        sb[i] = p.b_load_km(k0 + kr, n0 + (sub % V) * 8, sub / V, z);
+        const int ch = c0 + TP * i;
+        sb[i] = p.b_load_km(k0 + kr, n0 + (ch % V) * 8, ch / V, z);
       }
     }
   };
@@ -279,11 +281,12 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       for (int i = 0; i < NA; ++i)
         *reinterpret_cast<u32x4_t*>(As + plane * A_PLANE + (tid / (2 * KC) + RPP * i) * MKS + k8 * 16) = sa[i];
     } else {
-      constexpr int V = BM / 8, PER = 2 * V, RP = 256 / PER, S = KmStride<BM>::bytes;
+      constexpr int V = BM / 8, TP = 256 / BKT, S = KmStride<BM>::bytes;
+      const int kr = tid / TP, c0 = tid % TP;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int kr = tid / PER + RP * i, sub = tid % PER;
-        *reinterpret_cast<u32x4_t*>(As + (sub / V) * A_PLANE + kr * S + (sub % V) * 16) = sa[i];
+        const int ch = c0 + TP * i;
+        *reinterpret_cast<u32x4_t*>(As + (ch / V) * A_PLANE + kr * S + (ch % V) * 16) = sa[i];
       }
     }
     if constexpr (!P::B_KM) {
@@ -292,11 +295,12 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       for (int i = 0; i < NB; ++i)
         *reinterpret_cast<u32x4_t*>(Bs + plane * B_PLANE + (tid / (2 * KC) + RPP * i) * MKS + k8 * 16) = sb[i];
     } else {
-      constexpr int V = BN / 8, PER = 2 * V, RP = 256 / PER, S = KmStride<BN>::bytes;
+      constexpr int V = BN / 8, TP = 256 / BKT, S = KmStride<BN>::bytes;
+      const int kr = tid / TP, c0 = tid % TP;
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int kr = tid / PER + RP * i, sub = tid % PER;
-        *reinterpret_cast<u32x4_t*>(Bs + (sub / V) * B_PLANE + kr * S + (sub % V) * 16) = sb[i];
+        const int ch = c0 + TP * i;
+        *reinterpret_cast<u32x4_t*>(Bs + (ch / V) * B_PLANE + kr * S + (ch % V) * 16) = sb[i];
       }
     }
   };
