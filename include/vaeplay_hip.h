@@ -89,6 +89,11 @@ int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, 
                             int R, int C, int act, float slope, int batch_stats,
                             void* ws, size_t ws_bytes, vp_stream stream);
 int vp_nchw_to_nhwc_split_f32(const float* in, float* out, void* out_split, int B, int C, int H, int W, vp_stream stream);
+/* edge layers (1/3 image channels) on the bf16x3 path: the small-channel dimension zero-padded to a multiple of 8.
+ * p1_split = [Cbig][25][Csmall_pad] planes; dlogit_split = [npix][Cpad] planes next to the fp32 dlogit [npix][C]. */
+int vp_pack_w5_p1_split_padded(const float* w_ref, void* p1_split, int Csmall, int Cbig, int Csmall_pad, vp_stream stream);
+int vp_bce_sigmoid_bwd_pad_split_f32(const float* p, const float* t, float gscale, float* dlogit, void* dlogit_split,
+                                     size_t npix, int C, int Cpad, vp_stream stream);
 
 /* ---- dense layers ------------------------------------------------------------------------ */
 /* C[m][n] = bias[n] + sum_k A(m,k) B(n,k) with element strides (sam,sak) / (sbn,sbk).

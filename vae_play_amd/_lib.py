@@ -35,6 +35,8 @@ SIGNATURES = {
     "vp_bn_act_fwd_split_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),
     "vp_bn_act_bwd_split_f32": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, c_size_t, P]),
     "vp_nchw_to_nhwc_split_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vp_pack_w5_p1_split_padded": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "vp_bce_sigmoid_bwd_pad_split_f32": (c_int, [P, P, c_float, P, P, c_size_t, c_int, c_int, P]),
     "vp_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vp_gemm_f32": (c_int, [P, c_long, c_long, P, c_long, c_long, P, c_int, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "vp_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -118,39 +118,39 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
   }
 }
 
-// Finalize: 16 channels x 16 chunk-lanes per 256-thread block; each thread sums every 16th chunk
-// partial in fp64, an LDS tree combines the 16 lanes.  (A one-thread-per-channel loop over up to
-// 2048 chunks cost 185 us per call -- 3.7 ms of a 20 ms step -- in the first profile.)
-constexpr int FIN_C = 16, FIN_K = 16;
+// Finalize: 4 channels per 256-thread block, one wavefront (64 lanes) per channel; each lane sums every
+// 64th chunk partial in fp64 with two independent chains, then a shuffle reduction.  (The first version,
+// one thread per channel looping over up to 2048 chunks, cost 185 us per call; 16 lanes per channel
+// still 9.5 us.)
+constexpr int FIN_C = 4;
 
-__device__ __forceinline__ void bn_final_reduce(const float* __restrict__ part, int nchunk, int C, int c, int kl,
-                                                double (*sh)[FIN_K][FIN_C], double& s, double& q) {
-  s = 0.0; q = 0.0;
+__device__ __forceinline__ void bn_final_reduce(const float* __restrict__ part, int nchunk, int C, int c, int lane,
+                                                double& s, double& q) {
+  double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
   if (c < C) {
-    for (int k = kl; k < nchunk; k += FIN_K) {
-      s += (double)part[(size_t)k * C + c];
-      q += (double)part[((size_t)nchunk + k) * C + c];
+    int k = lane;
+    for (; k + 64 < nchunk; k += 128) {
+      s0 += (double)part[(size_t)k * C + c];
+      s1 += (double)part[(size_t)(k + 64) * C + c];
+      q0 += (double)part[((size_t)nchunk + k) * C + c];
+      q1 += (double)part[((size_t)nchunk + k + 64) * C + c];
+    }
+    if (k < nchunk) {
+      s0 += (double)part[(size_t)k * C + c];
+      q0 += (double)part[((size_t)nchunk + k) * C + c];
     }
   }
-  const int cl = threadIdx.x % FIN_C;
-  sh[0][kl][cl] = s;
-  sh[1][kl][cl] = q;
-  __syncthreads();
-  if (kl == 0) {
-    s = 0.0; q = 0.0;
-#pragma unroll
-    for (int k = 0; k < FIN_K; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
-  }
+  s = wave_sum_d(s0 + s1);
+  q = wave_sum_d(q0 + q1);
 }
 
 __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __restrict__ part, int nchunk, int R, int C, float eps,
                                                              float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                              float* __restrict__ rm, float* __restrict__ rv) {
-  __shared__ double sh[2][FIN_K][FIN_C];
-  const int c = blockIdx.x * FIN_C + threadIdx.x % FIN_C, kl = threadIdx.x / FIN_C;
+  const int c = blockIdx.x * FIN_C + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   double s, q;
-  bn_final_reduce(part, nchunk, C, c, kl, sh, s, q);
-  if (kl != 0 || c >= C) return;
+  bn_final_reduce(part, nchunk, C, c, lane, s, q);
+  if (lane != 0 || c >= C) return;
   const double m = s / R;
   double var = q / R - m * m;
   if (var < 0.0) var = 0.0;
@@ -166,11 +166,10 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __rest
 __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* __restrict__ part, int nchunk, int C,
                                                            float* __restrict__ sum_g, float* __restrict__ sum_gx,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double sh[2][FIN_K][FIN_C];
-  const int c = blockIdx.x * FIN_C + threadIdx.x % FIN_C, kl = threadIdx.x / FIN_C;
+  const int c = blockIdx.x * FIN_C + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   double s, q;
-  bn_final_reduce(part, nchunk, C, c, kl, sh, s, q);
-  if (kl != 0 || c >= C) return;
+  bn_final_reduce(part, nchunk, C, c, lane, s, q);
+  if (lane != 0 || c >= C) return;
   sum_g[c] = (float)s;
   sum_gx[c] = (float)q;
   if (dbeta) dbeta[c] = (float)s;

@@ -25,12 +25,15 @@ __global__ void split_kernel(const float* __restrict__ x, u16_t* __restrict__ ou
 //   MODE 0: p0[cs][t][cb] <- w[cs][cb][t]   (one cs, 64 cb per workgroup: 1600 contiguous floats in)
 //   MODE 1: p1[cb][t][cs] <- w[cs][cb][t]   (one cb, 64 cs per workgroup: 64 x 100-B segments in)
 // SPLIT: write bf16 hi/lo planes (plane stride n) instead of fp32.
+// CsP >= Cs: MODE 1 may zero-pad the small-channel (inner) dimension of p1 to CsP (edge layers on the bf16x3 path).
 template <int MODE, bool SPLIT>
-__global__ void __launch_bounds__(256) pack_w5_tiled_kernel(const float* __restrict__ w, void* __restrict__ outv, int Cs, int Cb) {
+__global__ void __launch_bounds__(256) pack_w5_tiled_kernel(const float* __restrict__ w, void* __restrict__ outv, int Cs, int Cb,
+                                                            int CsP) {
   __shared__ float tile[64][kTaps + 1];
-  const size_t n = (size_t)Cs * Cb * kTaps;
+  const size_t n = (size_t)(MODE == 1 ? CsP : Cs) * Cb * kTaps;
   const int fixed = blockIdx.x, j0 = blockIdx.y * 64;
   const int lim = (MODE == 0 ? Cb : Cs) - j0;           // valid entries of the 64-wide tile
+  const int lim_out = (MODE == 0 ? Cb : CsP) - j0;      // entries written (zeros beyond lim)
   for (int idx = threadIdx.x; idx < 64 * kTaps; idx += 256) {
     const int j = idx / kTaps, t = idx - j * kTaps;
     if (j < lim) {
@@ -39,12 +42,12 @@ __global__ void __launch_bounds__(256) pack_w5_tiled_kernel(const float* __restr
     }
   }
   __syncthreads();
-  const int inner = MODE == 0 ? Cb : Cs;
+  const int inner = MODE == 0 ? Cb : CsP;
   for (int idx = threadIdx.x; idx < 64 * kTaps; idx += 256) {
     const int t = idx >> 6, j = idx & 63;
-    if (j < lim) {
+    if (j < lim_out) {
       const size_t o = ((size_t)fixed * kTaps + t) * inner + j0 + j;
-      const float v = tile[j][t];
+      const float v = j < lim ? tile[j][t] : 0.f;
       if constexpr (SPLIT) {
         u16_t h, l;
         split_f32(v, h, l);
@@ -58,9 +61,10 @@ __global__ void __launch_bounds__(256) pack_w5_tiled_kernel(const float* __restr
 }
 
 template <bool SPLIT>
-static int pack_w5_launch(const float* w, void* p0, void* p1, int Cs, int Cb, hipStream_t s, const char* what) {
-  if (p0) hipLaunchKernelGGL((pack_w5_tiled_kernel<0, SPLIT>), dim3(Cs, (Cb + 63) / 64), dim3(256), 0, s, w, p0, Cs, Cb);
-  if (p1) hipLaunchKernelGGL((pack_w5_tiled_kernel<1, SPLIT>), dim3(Cb, (Cs + 63) / 64), dim3(256), 0, s, w, p1, Cs, Cb);
+static int pack_w5_launch(const float* w, void* p0, void* p1, int Cs, int Cb, hipStream_t s, const char* what, int CsP = 0) {
+  if (CsP < Cs) CsP = Cs;
+  if (p0) hipLaunchKernelGGL((pack_w5_tiled_kernel<0, SPLIT>), dim3(Cs, (Cb + 63) / 64), dim3(256), 0, s, w, p0, Cs, Cb, Cs);
+  if (p1) hipLaunchKernelGGL((pack_w5_tiled_kernel<1, SPLIT>), dim3(Cb, (CsP + 63) / 64), dim3(256), 0, s, w, p1, Cs, Cb, CsP);
   return check_launch(what);
 }
 
@@ -85,6 +89,12 @@ int vp_pack_w5_split(const float* w_ref, void* p0_split, void* p1_split, int Csm
   VP_REQUIRE(w_ref && (p0_split || p1_split) && Csmall > 0 && Cbig > 0, "vp_pack_w5_split: bad arguments");
   VP_REQUIRE(Csmall <= 65535 && Cbig <= 65535, "vp_pack_w5_split: channel count too large");
   return pack_w5_launch<true>(w_ref, p0_split, p1_split, Csmall, Cbig, (hipStream_t)stream, "vp_pack_w5_split");
+}
+
+int vp_pack_w5_p1_split_padded(const float* w_ref, void* p1_split, int Csmall, int Cbig, int Csmall_pad, vp_stream stream) {
+  VP_REQUIRE(w_ref && p1_split && Csmall > 0 && Cbig > 0 && Csmall_pad >= Csmall && Csmall_pad % 8 == 0,
+             "vp_pack_w5_p1_split_padded: bad arguments");
+  return pack_w5_launch<true>(w_ref, nullptr, p1_split, Csmall, Cbig, (hipStream_t)stream, "vp_pack_w5_p1_split_padded", Csmall_pad);
 }
 
 int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs,

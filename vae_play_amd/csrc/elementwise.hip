@@ -155,6 +155,26 @@ __global__ void bce_sigmoid_bwd_kernel(const float* __restrict__ p, const float*
   }
 }
 
+// dlogit = gscale*(p - t) as fp32 [npix][C] and, zero-padded to CP channels, as split bf16 planes
+// [npix][CP] (so that the 3-channel final-conv dgrad can run on the bf16x3 scatter kernel with K = 25*CP)
+__global__ void bce_sigmoid_bwd_pad_kernel(const float* __restrict__ p, const float* __restrict__ t, float gscale,
+                                           float* __restrict__ dl, u16_t* __restrict__ dl_split, size_t npix, int C, int CP) {
+  const size_t n = npix * CP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / CP;
+    const int c = (int)(i - pix * CP);
+    float v = 0.f;
+    if (c < C) {
+      v = gscale * (p[pix * C + c] - t[pix * C + c]);
+      dl[pix * C + c] = v;
+    }
+    u16_t h, l;
+    split_f32(v, h, l);
+    dl_split[i] = h;
+    dl_split[n + i] = l;
+  }
+}
+
 // torch.optim.Adam (single-tensor form): m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g;
 // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -270,6 +290,15 @@ int vp_bce_sigmoid_bwd_f32(const float* p, const float* t, float gscale, float* 
   VP_REQUIRE(p && t && dlogit && n > 0, "vp_bce_sigmoid_bwd_f32: bad arguments");
   hipLaunchKernelGGL(bce_sigmoid_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, p, t, gscale, dlogit, n);
   return check_launch("vp_bce_sigmoid_bwd_f32");
+}
+
+int vp_bce_sigmoid_bwd_pad_split_f32(const float* p, const float* t, float gscale, float* dlogit, void* dlogit_split,
+                                     size_t npix, int C, int Cpad, vp_stream stream) {
+  VP_REQUIRE(p && t && dlogit && dlogit_split && npix > 0 && C > 0 && Cpad >= C && Cpad % 8 == 0,
+             "vp_bce_sigmoid_bwd_pad_split_f32: bad arguments");
+  hipLaunchKernelGGL(bce_sigmoid_bwd_pad_kernel, dim3(grid_for(npix * Cpad, 256)), dim3(256), 0, (hipStream_t)stream, p, t, gscale,
+                     dlogit, (u16_t*)dlogit_split, npix, C, Cpad);
+  return check_launch("vp_bce_sigmoid_bwd_pad_split_f32");
 }
 
 int vp_adam_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,

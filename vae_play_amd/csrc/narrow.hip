@@ -71,11 +71,17 @@ __global__ void __launch_bounds__(256) conv5s1_smallout_kernel(const float* __re
   }
 }
 
-// slab[blk][tap][n][c] += sum over this workgroup's image rows; stride 1; c on the lane.
+// slab[blk][tap][n][c]; stride 1; c on the lane.  Work unit of a wavefront = a strip of NS_ROWS output rows
+// x one half of the image width.  Every input row of the strip (+2 halo rows either side) is loaded ONCE
+// through a 5-wide sliding register window and applied to all output rows it touches (up to 5 vertical
+// taps x 5 horizontal taps x NS channels = 75 FMAs per 256-B load).  The first version walked one output
+// row per wave and re-read each input row five times: 671 MB of L2 traffic, 22 TFLOP/s.
+constexpr int NS_ROWS = 4;
+
 template <int NS>
 __global__ void __launch_bounds__(256) wgrad_narrow_small_kernel(const float* __restrict__ big, const float* __restrict__ small,
                                                                  float* __restrict__ slab, int B, int H, int W, int Cb,
-                                                                 int rows_per_block) {
+                                                                 int nunits) {
   __shared__ float red[4][5 * NS][64];
   const int lane = threadIdx.x & 63;
   const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -85,39 +91,50 @@ __global__ void __launch_bounds__(256) wgrad_narrow_small_kernel(const float* __
   for (int t = 0; t < kTaps; ++t)
 #pragma unroll
     for (int n = 0; n < NS; ++n) acc[t][n] = 0.f;
-  const int nrows = B * H;
-  const int row0 = blockIdx.x * rows_per_block;
-  const int row1 = min(nrows, row0 + rows_per_block);
-  for (int row = row0 + g; row < row1; row += 4) {
-    const int b = row / H, h = row - b * H;
-    const float* sp = small + (size_t)row * W * NS;
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int hb = h + r - 2;
-      if (hb < 0 || hb >= H) continue;   // wave-uniform
+  const int unit = blockIdx.x * 4 + g;
+  if (unit < nunits) {
+    const int strips = (H + NS_ROWS - 1) / NS_ROWS;
+    const int half = unit & 1, su = unit >> 1;
+    const int b = su / strips, h0 = (su - b * strips) * NS_ROWS;
+    const int h1 = min(H, h0 + NS_ROWS);
+    const int wh = (W + 1) / 2;
+    const int xa = half * wh, xb = min(W, xa + wh);
+    for (int hb = max(0, h0 - 2); hb < min(H, h1 + 2) && xa < xb; ++hb) {
       const float* bp = big + ((size_t)(b * H + hb) * W) * Cb + c;
-      // sliding window over the row: win[j] = big[hb][x0 + j - 2]; four pixels per iteration so that four
-      // independent 256-B loads are in flight per wave (the one-pixel loop was latency-bound: 12 TFLOP/s)
+      // output row that vertical tap r of this input row feeds: h = hb + 2 - r
+      const float* sp[5];
+      bool on[5];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int h = hb + 2 - r;
+        on[r] = h >= h0 && h < h1;
+        sp[r] = small + ((size_t)(b * H + (on[r] ? h : h0)) * W) * NS;
+      }
       float win[8];
-      win[0] = 0.f; win[1] = 0.f;
-      win[2] = bp[0];
-      win[3] = W > 1 ? bp[Cb] : 0.f;
-      for (int x0 = 0; x0 < W; x0 += 4) {
+      win[0] = xa - 2 >= 0 ? bp[(size_t)(xa - 2) * Cb] : 0.f;
+      win[1] = xa - 1 >= 0 ? bp[(size_t)(xa - 1) * Cb] : 0.f;
+      win[2] = bp[(size_t)xa * Cb];
+      win[3] = xa + 1 < W ? bp[(size_t)(xa + 1) * Cb] : 0.f;
+      for (int x0 = xa; x0 < xb; x0 += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) win[4 + j] = (x0 + 2 + j < W) ? bp[(size_t)(x0 + 2 + j) * Cb] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (x0 + j < W) {
-            float sv[NS];
+        for (int r = 0; r < 5; ++r) {
+          if (!on[r]) continue;                  // wave-uniform
 #pragma unroll
-            for (int n = 0; n < NS; ++n) sv[n] = sp[(x0 + j) * NS + n];
+          for (int j = 0; j < 4; ++j) {
+            if (x0 + j < xb) {
+              float sv[NS];
 #pragma unroll
-            for (int n = 0; n < NS; ++n) {
-              acc[r * 5 + 0][n] = fmaf(win[j + 0], sv[n], acc[r * 5 + 0][n]);
-              acc[r * 5 + 1][n] = fmaf(win[j + 1], sv[n], acc[r * 5 + 1][n]);
-              acc[r * 5 + 2][n] = fmaf(win[j + 2], sv[n], acc[r * 5 + 2][n]);
-              acc[r * 5 + 3][n] = fmaf(win[j + 3], sv[n], acc[r * 5 + 3][n]);
-              acc[r * 5 + 4][n] = fmaf(win[j + 4], sv[n], acc[r * 5 + 4][n]);
+              for (int n = 0; n < NS; ++n) sv[n] = sp[r][(x0 + j) * NS + n];
+#pragma unroll
+              for (int n = 0; n < NS; ++n) {
+                acc[r * 5 + 0][n] = fmaf(win[j + 0], sv[n], acc[r * 5 + 0][n]);
+                acc[r * 5 + 1][n] = fmaf(win[j + 1], sv[n], acc[r * 5 + 1][n]);
+                acc[r * 5 + 2][n] = fmaf(win[j + 2], sv[n], acc[r * 5 + 2][n]);
+                acc[r * 5 + 3][n] = fmaf(win[j + 3], sv[n], acc[r * 5 + 3][n]);
+                acc[r * 5 + 4][n] = fmaf(win[j + 4], sv[n], acc[r * 5 + 4][n]);
+              }
             }
           }
         }
@@ -144,11 +161,16 @@ __global__ void __launch_bounds__(256) wgrad_narrow_small_kernel(const float* __
   }
 }
 
-// slab[blk][tap][c][n] ; stride 2; dy channel c on the lane, x (NB channels) via uniform loads.
+// slab[blk][tap][c][n]; dy channel c on the lane.  The 5 x 5*NB input window of a pixel (75 floats for
+// NB = 3) is fetched by two vector loads spread over the lanes and each value is broadcast into the
+// scalar operand of the FMA with v_readlane; loads run one pixel ahead of the FMAs.  (The first version
+// issued 75 wave-uniform loads per pixel and ran at 7 TFLOP/s.)
 template <int NB>
 __global__ void __launch_bounds__(256) wgrad_narrow_big_kernel(const float* __restrict__ big, const float* __restrict__ small,
                                                                float* __restrict__ slab, int B, int H, int W, int Cs,
                                                                int stride, int rows_per_block) {
+  constexpr int NE = 5 * NB;      // window elements per tap row
+  constexpr int NT = 5 * NE;      // window elements per pixel (<= 75)
   __shared__ float red[4][5 * NB][64];
   const int lane = threadIdx.x & 63;
   const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -159,27 +181,42 @@ __global__ void __launch_bounds__(256) wgrad_narrow_big_kernel(const float* __re
   for (int t = 0; t < kTaps; ++t)
 #pragma unroll
     for (int n = 0; n < NB; ++n) acc[t][n] = 0.f;
+  // this lane's window element(s): l0 = lane, l1 = lane + 64
+  const int r0 = lane / NE, e0 = lane - r0 * NE;
+  const int l1 = lane + 64;
+  const int r1 = l1 / NE, e1 = l1 - r1 * NE;
+  const bool has0 = lane < NT, has1 = l1 < NT;
   const int nrows = B * H;
   const int row0 = blockIdx.x * rows_per_block;
   const int row1 = min(nrows, row0 + rows_per_block);
   for (int row = row0 + g; row < row1; row += 4) {
     const int b = row / H, h = row - b * H;
     const float* sp = small + (size_t)row * W * Cs + c;
+    const int hb0 = stride * h - 2 + r0, hb1 = stride * h - 2 + r1;
+    const bool rok0 = has0 && hb0 >= 0 && hb0 < Hb, rok1 = has1 && hb1 >= 0 && hb1 < Hb;
+    const float* base0 = big + ((size_t)(b * Hb + (rok0 ? hb0 : 0)) * Wb) * NB;
+    const float* base1 = big + ((size_t)(b * Hb + (rok1 ? hb1 : 0)) * Wb) * NB;
+    auto win = [&](int x, float& v0, float& v1, float& dyv) {
+      const int col0 = stride * x - 2 + e0 / NB, col1 = stride * x - 2 + e1 / NB;
+      v0 = (rok0 && col0 >= 0 && col0 < Wb) ? base0[(size_t)col0 * NB + e0 % NB] : 0.f;
+      v1 = (rok1 && col1 >= 0 && col1 < Wb) ? base1[(size_t)col1 * NB + e1 % NB] : 0.f;
+      dyv = sp[(size_t)x * Cs];
+    };
+    float v0, v1, dyv;
+    win(0, v0, v1, dyv);
     for (int x = 0; x < W; ++x) {
-      const float dyv = sp[(size_t)x * Cs];
+      float n0 = 0.f, n1 = 0.f, ndy = 0.f;
+      if (x + 1 < W) win(x + 1, n0, n1, ndy);
 #pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        const int hb = stride * h + r - 2;
-        if (hb < 0 || hb >= Hb) continue;
-        const float* brow = big + ((size_t)(b * Hb + hb) * Wb) * NB;
+      for (int t = 0; t < kTaps; ++t)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-          const int wb = stride * x + q - 2;
-          if (wb < 0 || wb >= Wb) continue;
-#pragma unroll
-          for (int n = 0; n < NB; ++n) acc[r * 5 + q][n] = fmaf(dyv, brow[(size_t)wb * NB + n], acc[r * 5 + q][n]);
+        for (int n = 0; n < NB; ++n) {
+          const int idx = (t / 5) * NE + (t % 5) * NB + n;      // compile-time after unrolling
+          const float src = idx < 64 ? v0 : v1;
+          const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), idx & 63));
+          acc[t][n] = fmaf(dyv, sv, acc[t][n]);
         }
-      }
+      v0 = n0; v1 = n1; dyv = ndy;
     }
   }
   float* dst = slab + (size_t)blockIdx.x * kTaps * Cs * NB;
@@ -249,22 +286,27 @@ int narrow_wgrad_kind(const ConvGeom& g) {
   return 0;
 }
 
-size_t narrow_wgrad_ws_floats(const ConvGeom& g) {
+static int narrow_small_units(const ConvGeom& g) { return g.B * ((g.Hs + NS_ROWS - 1) / NS_ROWS) * 2; }
+
+static int narrow_wgrad_nblk(const ConvGeom& g) {
+  if (narrow_wgrad_kind(g) == 1) return (narrow_small_units(g) + 3) / 4;
   const int rpb = narrow_rows_per_block(g);
-  const int nblk = (g.B * g.Hs + rpb - 1) / rpb;
-  return (size_t)nblk * kTaps * g.Cs * g.Cb;
+  return (g.B * g.Hs + rpb - 1) / rpb;
 }
+
+size_t narrow_wgrad_ws_floats(const ConvGeom& g) { return (size_t)narrow_wgrad_nblk(g) * kTaps * g.Cs * g.Cb; }
 
 int narrow_wgrad_launch(const float* big, const float* small, float* dw_ref, const ConvGeom& g, float* ws, hipStream_t s) {
   const int kind = narrow_wgrad_kind(g);
   const int rpb = narrow_rows_per_block(g);
-  const int nblk = (g.B * g.Hs + rpb - 1) / rpb;
+  const int nblk = narrow_wgrad_nblk(g);
   if (kind == 1) {
     dim3 grid(nblk, g.Cb / 64);
+    const int nunits = narrow_small_units(g);
     if (g.Cs == 3)
-      hipLaunchKernelGGL((wgrad_narrow_small_kernel<3>), grid, dim3(256), 0, s, big, small, ws, g.B, g.Hs, g.Ws, g.Cb, rpb);
+      hipLaunchKernelGGL((wgrad_narrow_small_kernel<3>), grid, dim3(256), 0, s, big, small, ws, g.B, g.Hs, g.Ws, g.Cb, nunits);
     else
-      hipLaunchKernelGGL((wgrad_narrow_small_kernel<1>), grid, dim3(256), 0, s, big, small, ws, g.B, g.Hs, g.Ws, g.Cb, rpb);
+      hipLaunchKernelGGL((wgrad_narrow_small_kernel<1>), grid, dim3(256), 0, s, big, small, ws, g.B, g.Hs, g.Ws, g.Cb, nunits);
   } else {
     dim3 grid(nblk, g.Cs / 64);
     if (g.Cb == 3)

@@ -448,8 +448,8 @@ inline ProbT make_probT(const float* small, const float* wp1, float* out, const 
 inline int wgrad_nsplit(const ConvGeom& g) {
   long K = (long)g.B * g.Hs * g.Ws;
   long tiles = ((g.Cs + 127) / 128) * (long)((g.Cb + 127) / 128) * kTaps;
-  long want = (768 + tiles - 1) / tiles;
-  long maxs = (K + 255) / 256;  // keep >= 8 K-tiles of 32 per split
+  long want = (512 + tiles - 1) / tiles;
+  long maxs = (K + 511) / 512;  // keep >= 16 K-tiles of 32 per split
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
   if (s > 64) s = 64;

@@ -257,7 +257,14 @@ class FusedVAEStep:
         # ---------------- backward ----------------
         inv_b = 1.0 / B
         dlogit = self._buf("g.dlogit", n_pix)
-        bwd.add("vp_bce_sigmoid_bwd_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), n_pix)
+        fin16 = x3 and Cf % 8 == 0 and C < 8          # final-conv dgrad on the bf16x3 kernel with dlogit padded to 8 channels
+        if fin16:
+            dlogit_s = self._sbuf("g.dlogit_s", B * S * S * 8)
+            fp1s = self._sbuf("fin.p1s", Cf * 25 * 8)
+            fwd.add("vp_pack_w5_p1_split_padded", P(fin.weight), P(fp1s), C, Cf, 8)
+            bwd.add("vp_bce_sigmoid_bwd_pad_split_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), P(dlogit_s), B * S * S, C, 8)
+        else:
+            bwd.add("vp_bce_sigmoid_bwd_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), n_pix)
         ws_cs = self._ws("g.colsum.ws", lib.vp_colsum_workspace_bytes(B * S * S, C))
         bwd.add("vp_colsum_f32", P(dlogit), P(grad_of(fin.bias)), B * S * S, C, P(ws_cs), ws_cs.numel() * 4)
         ws_wg = self._ws("g.wgrad.ws", self._max_wgrad_ws(enc_rec, dec_rec, Cf))
@@ -267,7 +274,10 @@ class FusedVAEStep:
         big = max([B * F0, B * F1, n_pix] + [B * 4 * r[3] * r[3] * r[2] for r in dec_rec] + [B * r[3] * r[3] * r[2] for r in enc_rec]
                   + [B * S * S * Cf])
         gA, gB = self._buf("g.A", big), self._buf("g.B", big)
-        bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
+        if fin16:
+            bwd.add("vp_conv5_scatter_bf16x3", P(dlogit_s), P(fp1s), P(gA), B, S, S, 8, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
+        else:
+            bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         cur, other = gA, gB
         gS = self._sbuf("g.S", big) if x3 else None     # split gradient (output of BN backward) for the 16-bit kernels
         for i in range(L - 1, -1, -1):
