@@ -110,7 +110,7 @@ int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const 
   p.w = (const u16*)w_p0_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
   p.bias = bias; p.out = small_out; p.act = act;
   p.M = B * Hs * Ws; p.N = Csmall; p.K = kTaps * Cbig;
-  launch_igemm16(p, p.M, p.N, 1, (hipStream_t)stream);
+  launch_igemm16(p, p.M, p.N, 1, (hipStream_t)stream, Cbig);
   return check_launch("vp_conv5_gather_bf16x3");
 }
 
@@ -125,7 +125,7 @@ int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, flo
   p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
   p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
   p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
-  launch_igemm16(p, p.M, p.N, stride * stride, (hipStream_t)stream);
+  launch_igemm16(p, p.M, p.N, stride * stride, (hipStream_t)stream, Csmall);
   return check_launch("vp_conv5_scatter_bf16x3");
 }
 

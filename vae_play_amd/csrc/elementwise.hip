@@ -6,9 +6,9 @@
 
 namespace vp {
 
-// 64 zero bytes in global memory: the "zero page" that out-of-range gathers of the implicit-GEMM kernels
+// 512 zero bytes in global memory (a padded row's chunks are read at offsets up to 128 B): the "zero page" that out-of-range gathers of the implicit-GEMM kernels
 // read (problems.h).  A __device__ symbol of this code object, not an allocation.
-__device__ __attribute__((aligned(64))) unsigned int vp_zero_page_storage[16] = {0};
+__device__ __attribute__((aligned(64))) unsigned int vp_zero_page_storage[128] = {0};
 
 const void* vp_zero_page() {
   static const void* ptr = [] {

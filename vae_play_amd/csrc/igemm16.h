@@ -78,20 +78,42 @@ struct ProbF16 {
     r.pix_base = b * g.Hb * g.Wb; r.h0 = g.stride * hs - 2; r.w0 = g.stride * ws - 2;
     return r;
   }
-  // every gather is branch-free: the load is always issued (address clamped to element 0 of the plane)
-  // and the result is zero-selected afterwards, so a K-tile's loads are issued back to back
-  VP_HD u32x4_t a_load(const ARow& r, int k, int plane, const ZCtx&) const {
-    int tap = (int)g.dCb.div((uint32_t)k), c = k - tap * g.Cb;
-    int rr = div_small(tap, 5), qq = tap - rr * 5;
-    int h = r.h0 + rr, w_ = r.w0 + qq;
-    const bool ok = r.valid && k < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+  // Every gather is branch-free: out-of-range chunks read the zero page, so a K-tile's loads are issued
+  // back to back.  FAST (channel count a multiple of the K-tile depth): the whole tile [k0, k0+BKT) lies
+  // inside ONE tap, so tap -> (rr, qq) is computed from the workgroup-uniform k0 on the scalar unit; only
+  // the bounds test and the address remain per-lane work (VALU per MFMA fell from 5-13 to ~3, PMC).
+  template <bool FAST>
+  VP_HD u32x4_t a_load(const ARow& r, int k0, int k8, int plane, const ZCtx&) const {
+    const int kt = FAST ? k0 : k0 + k8;
+    const int tap = (int)g.dCb.div((uint32_t)kt);
+    const int c = k0 + k8 - tap * g.Cb;
+    const int rr = div_small(tap, 5), qq = tap - rr * 5;
+    const int h = r.h0 + rr, w_ = r.w0 + qq;
+    const bool ok = r.valid && kt < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
     return ld16(ok ? big + plane * big_plane + (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c : reinterpret_cast<const u16*>(zero));
   }
   VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * K; return r; }
-  VP_HD u32x4_t b_load(const BRow& r, int k, int plane, const ZCtx&) const {
-    const bool ok = r.valid && k < K;
-    return ld16(ok ? w + plane * w_plane + (size_t)r.off + k : reinterpret_cast<const u16*>(zero));
+  template <bool FAST>
+  VP_HD u32x4_t b_load(const BRow& r, int k0, int k8, int plane, const ZCtx&) const {
+    const bool ok = r.valid && (FAST ? k0 : k0 + k8) < K;
+    return ld16(ok ? w + plane * w_plane + (size_t)r.off + k0 + k8 : reinterpret_cast<const u16*>(zero));
   }
+  // FAST row-level form: one bounds test + one address per (row, K-tile); the caller adds plane / chunk offsets
+  VP_HD bool a_base(const ARow& r, int k0, const ZCtx&, size_t& off) const {
+    const int tap = (int)g.dCb.div((uint32_t)k0);          // workgroup-uniform -> scalar unit
+    const int rr = div_small(tap, 5), qq = tap - rr * 5;
+    const int h = r.h0 + rr, w_ = r.w0 + qq;
+    off = (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + (k0 - tap * g.Cb);
+    return r.valid && k0 < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+  }
+  VP_HD bool b_base(const BRow& r, int k0, const ZCtx&, size_t& off) const {
+    off = (size_t)r.off + k0;
+    return r.valid && k0 < K;
+  }
+  VP_HD const u16* a_ptr() const { return big; }
+  VP_HD size_t a_plane() const { return big_plane; }
+  VP_HD const u16* b_ptr() const { return w; }
+  VP_HD size_t b_plane() const { return w_plane; }
   VP_HD void store(int m, int n, float v, const ZCtx&) const {
     if (m >= M || n >= N) return;
     if (bias) v += bias[n];
@@ -120,22 +142,47 @@ struct ProbT16 {
     r.q = (int)g.dW.div((uint32_t)rem); r.p = rem - r.q * g.Ws; r.pix_base = b * g.Hs * g.Ws;
     return r;
   }
-  VP_HD u32x4_t a_load(const ARow& r, int k, int plane, const ZCtx& z) const {
-    int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
-    int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-    int d0 = g.stride == 2 ? 1 : 2;
-    int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
-    const bool ok = r.valid && k < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
+  template <bool FAST>
+  VP_HD u32x4_t a_load(const ARow& r, int k0, int k8, int plane, const ZCtx& z) const {
+    const int kt = FAST ? k0 : k0 + k8;
+    const int t = (int)g.dCs.div((uint32_t)kt);
+    const int c = k0 + k8 - t * g.Cs;
+    const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
+    const int d0 = g.stride == 2 ? 1 : 2;
+    const int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+    const bool ok = r.valid && kt < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
     return ld16(ok ? small + plane * small_plane + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : reinterpret_cast<const u16*>(zero));
   }
   VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * kTaps * g.Cs; return r; }
-  VP_HD u32x4_t b_load(const BRow& r, int k, int plane, const ZCtx& z) const {
-    int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
-    int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-    int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
-    const bool ok = r.valid && k < z.k_end;
+  template <bool FAST>
+  VP_HD u32x4_t b_load(const BRow& r, int k0, int k8, int plane, const ZCtx& z) const {
+    const int kt = FAST ? k0 : k0 + k8;
+    const int t = (int)g.dCs.div((uint32_t)kt);
+    const int c = k0 + k8 - t * g.Cs;
+    const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
+    const int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+    const bool ok = r.valid && kt < z.k_end;
     return ld16(ok ? w + plane * w_plane + (size_t)r.off + tap * g.Cs + c : reinterpret_cast<const u16*>(zero));
   }
+  VP_HD bool a_base(const ARow& r, int k0, const ZCtx& z, size_t& off) const {
+    const int t = (int)g.dCs.div((uint32_t)k0);
+    const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
+    const int d0 = g.stride == 2 ? 1 : 2;
+    const int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+    off = (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + (k0 - t * g.Cs);
+    return r.valid && k0 < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
+  }
+  VP_HD bool b_base(const BRow& r, int k0, const ZCtx& z, size_t& off) const {
+    const int t = (int)g.dCs.div((uint32_t)k0);
+    const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
+    const int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+    off = (size_t)r.off + tap * g.Cs + (k0 - t * g.Cs);
+    return r.valid && k0 < z.k_end;
+  }
+  VP_HD const u16* a_ptr() const { return small; }
+  VP_HD size_t a_plane() const { return small_plane; }
+  VP_HD const u16* b_ptr() const { return w; }
+  VP_HD size_t b_plane() const { return w_plane; }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
     int b = (int)g.dHW.div((uint32_t)m); int rem = m - b * (g.Hs * g.Ws);
@@ -205,7 +252,7 @@ __device__ __forceinline__ bf16x8_t frag16(const unsigned char* plane, int row, 
   }
 }
 
-template <class P, int BM, int BN, int WM, int WN, int BKT>
+template <class P, int BM, int BN, int WM, int WN, int BKT, bool FAST>
 __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(BKT == 32 || BKT == 64, "K-tile depth");
@@ -216,7 +263,15 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   constexpr int A_PLANE = Lds16<BM, P::A_KM, BKT>::plane_bytes;
   constexpr int B_PLANE = Lds16<BN, P::B_KM, BKT>::plane_bytes;
   constexpr int MKS = MkStride<BKT>::bytes;
-  constexpr int RPP = 256 / (2 * KC);         // MK rows staged per pass
+  // MK staging map: 4 threads per row; a thread stages, for BM/64 (BN/64) rows, CPT chunks of the row:
+  // both planes x the k-chunks {l4*CPH .. l4*CPH+CPH-1}.  One bounds test / address per row serves all
+  // its chunks (FAST path), a 4-lane group reads 64 contiguous bytes per plane, and an 8-lane
+  // ds_write_b128 group (2 rows x 4 lanes) covers 32 distinct banks.
+  constexpr int TPR = 4, RPP = 256 / TPR;     // 64 rows per pass
+  constexpr int CPT = 2 * KC / TPR, CPH = CPT / 2;   // chunks per thread per row / per plane
+  constexpr int NRA = BM / RPP, NRB = BN / RPP;
+  static_assert(P::A_KM || (NRA >= 1 && NRA * CPT == NA), "MK staging map (A)");
+  static_assert(P::B_KM || (NRB >= 1 && NRB * CPT == NB), "MK staging map (B)");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_PLANE + 2 * B_PLANE];
   unsigned char* As = lds;                   // [plane][...]
   unsigned char* Bs = lds + 2 * A_PLANE;
@@ -232,23 +287,41 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 
   // staging map.  MK: chunk = (row = tid/(2*KC) + RPP*i, sub = tid%(2*KC) -> plane = sub/KC, k8 = sub%KC)
   //               KM: chunk = (krow, col8, plane) with V = BR/8 chunks per k-row and plane
-  Rows16A<P, NA, P::A_KM> ra;
-  Rows16B<P, NB, P::B_KM> rb;
+  Rows16A<P, (P::A_KM ? 1 : NRA), P::A_KM> ra;
+  Rows16B<P, (P::B_KM ? 1 : NRB), P::B_KM> rb;
+  const int l4 = tid % TPR, srow = tid / TPR;
   if constexpr (!P::A_KM) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra.r[i] = p.a_row(m0 + tid / (2 * KC) + RPP * i, z);
+    for (int i = 0; i < NRA; ++i) ra.r[i] = p.a_row(m0 + srow + RPP * i, z);
   }
   if constexpr (!P::B_KM) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb.r[i] = p.b_row(n0 + tid / (2 * KC) + RPP * i, z);
+    for (int i = 0; i < NRB; ++i) rb.r[i] = p.b_row(n0 + srow + RPP * i, z);
   }
   u32x4_t sa[NA], sb[NB];
 
   auto stage_load = [&](int k0) {
     if constexpr (!P::A_KM) {
-      const int plane = (tid % (2 * KC)) / KC, k8 = (tid % KC) * 8;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) sa[i] = p.a_load(ra.r[i], k0 + k8, plane, z);
+      for (int i = 0; i < NRA; ++i) {
+        if constexpr (FAST) {
+          size_t off;
+          const bool ok = p.a_base(ra.r[i], k0, z, off);
+          const u16* b0 = ok ? p.a_ptr() + off : reinterpret_cast<const u16*>(p.zero);
+          const u16* b1 = ok ? p.a_ptr() + p.a_plane() + off : reinterpret_cast<const u16*>(p.zero);
+#pragma unroll
+          for (int j = 0; j < CPH; ++j) {
+            sa[i * CPT + j] = ld16(b0 + (l4 * CPH + j) * 8);
+            sa[i * CPT + CPH + j] = ld16(b1 + (l4 * CPH + j) * 8);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CPH; ++j) {
+            sa[i * CPT + j] = p.template a_load<false>(ra.r[i], k0, (l4 * CPH + j) * 8, 0, z);
+            sa[i * CPT + CPH + j] = p.template a_load<false>(ra.r[i], k0, (l4 * CPH + j) * 8, 1, z);
+          }
+        }
+      }
     } else {
       // one pixel (k-row) per thread and K-tile: TP threads share a pixel and each stages NA of its
       // 16-B chunks, so the pixel -> (b, h, w) decomposition is done once, not once per chunk
@@ -261,9 +334,26 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       }
     }
     if constexpr (!P::B_KM) {
-      const int plane = (tid % (2 * KC)) / KC, k8 = (tid % KC) * 8;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) sb[i] = p.b_load(rb.r[i], k0 + k8, plane, z);
+      for (int i = 0; i < NRB; ++i) {
+        if constexpr (FAST) {
+          size_t off;
+          const bool ok = p.b_base(rb.r[i], k0, z, off);
+          const u16* b0 = ok ? p.b_ptr() + off : reinterpret_cast<const u16*>(p.zero);
+          const u16* b1 = ok ? p.b_ptr() + p.b_plane() + off : reinterpret_cast<const u16*>(p.zero);
+#pragma unroll
+          for (int j = 0; j < CPH; ++j) {
+            sb[i * CPT + j] = ld16(b0 + (l4 * CPH + j) * 8);
+            sb[i * CPT + CPH + j] = ld16(b1 + (l4 * CPH + j) * 8);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CPH; ++j) {
+            sb[i * CPT + j] = p.template b_load<false>(rb.r[i], k0, (l4 * CPH + j) * 8, 0, z);
+            sb[i * CPT + CPH + j] = p.template b_load<false>(rb.r[i], k0, (l4 * CPH + j) * 8, 1, z);
+          }
+        }
+      }
     } else {
       constexpr int V = BN / 8, TP = 256 / BKT;
       const int kr = tid / TP, c0 = tid % TP;
@@ -276,10 +366,14 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   };
   auto stage_write = [&]() {
     if constexpr (!P::A_KM) {
-      const int plane = (tid % (2 * KC)) / KC, k8 = tid % KC;
 #pragma unroll
-      for (int i = 0; i < NA; ++i)
-        *reinterpret_cast<u32x4_t*>(As + plane * A_PLANE + (tid / (2 * KC) + RPP * i) * MKS + k8 * 16) = sa[i];
+      for (int i = 0; i < NRA; ++i)
+#pragma unroll
+        for (int j = 0; j < CPH; ++j) {
+          unsigned char* dst = As + (srow + RPP * i) * MKS + (l4 * CPH + j) * 16;
+          *reinterpret_cast<u32x4_t*>(dst) = sa[i * CPT + j];
+          *reinterpret_cast<u32x4_t*>(dst + A_PLANE) = sa[i * CPT + CPH + j];
+        }
     } else {
       constexpr int V = BM / 8, TP = 256 / BKT, S = KmStride<BM>::bytes;
       const int kr = tid / TP, c0 = tid % TP;
@@ -290,10 +384,14 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       }
     }
     if constexpr (!P::B_KM) {
-      const int plane = (tid % (2 * KC)) / KC, k8 = tid % KC;
 #pragma unroll
-      for (int i = 0; i < NB; ++i)
-        *reinterpret_cast<u32x4_t*>(Bs + plane * B_PLANE + (tid / (2 * KC) + RPP * i) * MKS + k8 * 16) = sb[i];
+      for (int i = 0; i < NRB; ++i)
+#pragma unroll
+        for (int j = 0; j < CPH; ++j) {
+          unsigned char* dst = Bs + (srow + RPP * i) * MKS + (l4 * CPH + j) * 16;
+          *reinterpret_cast<u32x4_t*>(dst) = sb[i * CPT + j];
+          *reinterpret_cast<u32x4_t*>(dst + B_PLANE) = sb[i * CPT + CPH + j];
+        }
     } else {
       constexpr int V = BN / 8, TP = 256 / BKT, S = KmStride<BN>::bytes;
       const int kr = tid / TP, c0 = tid % TP;
@@ -385,24 +483,32 @@ inline int igemm16_bk(bool km) {
   return km ? 32 : 64;
 }
 
-template <class P, int BKT>
+template <class P, int BKT, bool FAST>
 inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t stream) {
   Tile16 t = choose_tile16(M, N, gz);
   dim3 block(256);
   auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
   if (t.bm == 128 && t.bn == 128) {
-    hipLaunchKernelGGL((igemm16_kernel<P, 128, 128, 2, 2, BKT>), grid(128, 128), block, 0, stream, p);
+    hipLaunchKernelGGL((igemm16_kernel<P, 128, 128, 2, 2, BKT, FAST>), grid(128, 128), block, 0, stream, p);
   } else if (t.bm == 128 && t.bn == 64) {
-    hipLaunchKernelGGL((igemm16_kernel<P, 128, 64, 2, 2, BKT>), grid(128, 64), block, 0, stream, p);
+    hipLaunchKernelGGL((igemm16_kernel<P, 128, 64, 2, 2, BKT, FAST>), grid(128, 64), block, 0, stream, p);
   } else {
-    hipLaunchKernelGGL((igemm16_kernel<P, 64, 64, 2, 2, BKT>), grid(64, 64), block, 0, stream, p);
+    hipLaunchKernelGGL((igemm16_kernel<P, 64, 64, 2, 2, BKT, FAST>), grid(64, 64), block, 0, stream, p);
   }
 }
 
+// ctile = the channel count that k is decomposed by (0 for the pixel-major wgrad family): FAST kernels
+// are used when it is a multiple of the K-tile depth.
 template <class P>
-inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t stream) {
-  if (igemm16_bk(P::A_KM) == 32) launch_igemm16_bk<P, 32>(p, M, N, gz, stream);
-  else launch_igemm16_bk<P, 64>(p, M, N, gz, stream);
+inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0) {
+  const int bk = igemm16_bk(P::A_KM);
+  if (bk == 32) {
+    launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
+  } else if (!P::A_KM && ctile > 0 && ctile % 64 == 0) {
+    if constexpr (!P::A_KM) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream);
+  } else {
+    launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
+  }
 }
 #endif  // __HIPCC__
 
