@@ -99,15 +99,28 @@ struct ProbF16 {
     return ld16(ok ? w + plane * w_plane + (size_t)r.off + k0 + k8 : reinterpret_cast<const u16*>(zero));
   }
   // FAST row-level form: one bounds test + one address per (row, K-tile); the caller adds plane / chunk offsets
+  // FAST K order is CHANNEL-CHUNK major, tap minor: K-tile index kt -> (cc = kt / 25, tap = kt % 25).  The 25
+  // taps of one 64-channel chunk gather overlapping pixels back to back, so the re-reads hit the per-XCD L2
+  // (tap-major order re-reads a pixel only after a full channel sweep -- far more than 4 MB per XCD -- and
+  // every conv kernel then streamed its operands at the same ~10 TB/s regardless of tile shape).
+  VP_HD void fast_tile(int k0, int ntap, int& tap, int& c0) const {
+    const int kt = k0 >> 6;
+    const int cc = kt / ntap;            // scalar: k0 and ntap are workgroup-uniform
+    tap = kt - cc * ntap;
+    c0 = cc << 6;
+  }
   VP_HD bool a_base(const ARow& r, int k0, const ZCtx&, size_t& off) const {
-    const int tap = (int)g.dCb.div((uint32_t)k0);          // workgroup-uniform -> scalar unit
+    int tap, c0;
+    fast_tile(k0, kTaps, tap, c0);
     const int rr = div_small(tap, 5), qq = tap - rr * 5;
     const int h = r.h0 + rr, w_ = r.w0 + qq;
-    off = (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + (k0 - tap * g.Cb);
+    off = (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c0;
     return r.valid && k0 < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
   }
   VP_HD bool b_base(const BRow& r, int k0, const ZCtx&, size_t& off) const {
-    off = (size_t)r.off + k0;
+    int tap, c0;
+    fast_tile(k0, kTaps, tap, c0);
+    off = (size_t)r.off + tap * g.Cb + c0;
     return r.valid && k0 < K;
   }
   VP_HD const u16* a_ptr() const { return big; }
@@ -164,19 +177,27 @@ struct ProbT16 {
     const bool ok = r.valid && kt < z.k_end;
     return ld16(ok ? w + plane * w_plane + (size_t)r.off + tap * g.Cs + c : reinterpret_cast<const u16*>(zero));
   }
+  VP_HD void fast_tile(int k0, int ntap, int& t, int& c0) const {   // channel-chunk major, tap minor (see ProbF16)
+    const int kt = k0 >> 6;
+    const int cc = kt / ntap;
+    t = kt - cc * ntap;
+    c0 = cc << 6;
+  }
   VP_HD bool a_base(const ARow& r, int k0, const ZCtx& z, size_t& off) const {
-    const int t = (int)g.dCs.div((uint32_t)k0);
+    int t, c0;
+    fast_tile(k0, z.th * z.tw, t, c0);
     const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
     const int d0 = g.stride == 2 ? 1 : 2;
     const int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
-    off = (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + (k0 - t * g.Cs);
+    off = (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c0;
     return r.valid && k0 < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
   }
   VP_HD bool b_base(const BRow& r, int k0, const ZCtx& z, size_t& off) const {
-    const int t = (int)g.dCs.div((uint32_t)k0);
+    int t, c0;
+    fast_tile(k0, z.th * z.tw, t, c0);
     const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
     const int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
-    off = (size_t)r.off + tap * g.Cs + (k0 - t * g.Cs);
+    off = (size_t)r.off + tap * g.Cs + c0;
     return r.valid && k0 < z.k_end;
   }
   VP_HD const u16* a_ptr() const { return small; }
@@ -216,6 +237,22 @@ struct ProbW16 {
     const bool ok = k < z.k_end && n < N && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
     return ld16(ok ? big + plane * big_plane + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb + n : reinterpret_cast<const u16*>(zero));
   }
+  // FAST row-level form (tile fully inside M x N): element offset of channel 0 of pixel k
+  VP_HD bool a_base_km(int k, const ZCtx& z, size_t& off) const {
+    off = (size_t)k * g.Cs;
+    return k < z.k_end;
+  }
+  VP_HD bool b_base_km(int k, const ZCtx& z, size_t& off) const {
+    int b = (int)g.dHW.div((uint32_t)k); int rem = k - b * (g.Hs * g.Ws);
+    int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
+    int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
+    off = ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb;
+    return k < z.k_end && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+  }
+  VP_HD const u16* a_ptr() const { return small; }
+  VP_HD size_t a_plane() const { return small_plane; }
+  VP_HD const u16* b_ptr() const { return big; }
+  VP_HD size_t b_plane() const { return big_plane; }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
     slab[(((size_t)z.split * kTaps + z.tap) * M + m) * N + n] = v;
@@ -256,6 +293,7 @@ template <class P, int BM, int BN, int WM, int WN, int BKT, bool FAST>
 __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(BKT == 32 || BKT == 64, "K-tile depth");
+  static_assert(!FAST || P::A_KM || BKT == 64, "FAST gather/scatter kernels decompose k0 in 64-deep tiles");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
   constexpr int KC = BKT / 8;                 // 16-B chunks per row and plane
@@ -327,10 +365,22 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       // 16-B chunks, so the pixel -> (b, h, w) decomposition is done once, not once per chunk
       constexpr int V = BM / 8, TP = 256 / BKT;
       const int kr = tid / TP, c0 = tid % TP;
+      if constexpr (FAST) {
+        size_t off;
+        const bool ok = p.a_base_km(k0 + kr, z, off);
+        const u16* b0 = ok ? p.a_ptr() + off + m0 : reinterpret_cast<const u16*>(p.zero);
+        const u16* b1 = ok ? p.a_ptr() + p.a_plane() + off + m0 : reinterpret_cast<const u16*>(p.zero);
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int ch = c0 + TP * i;             // chunk index inside the pixel: [plane][V]
-        sa[i] = p.a_load_km(k0 + kr, m0 + (ch % V) * 8, ch / V, z);
+        for (int i = 0; i < NA; ++i) {
+          const int ch = c0 + TP * i;
+          sa[i] = ld16((ch / V ? b1 : b0) + (ch % V) * 8);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int ch = c0 + TP * i;             // chunk index inside the pixel: [plane][V]
+          sa[i] = p.a_load_km(k0 + kr, m0 + (ch % V) * 8, ch / V, z);
+        }
       }
     }
     if constexpr (!P::B_KM) {
@@ -357,10 +407,22 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
     } else {
       constexpr int V = BN / 8, TP = 256 / BKT;
       const int kr = tid / TP, c0 = tid % TP;
+      if constexpr (FAST) {
+        size_t off;
+        const bool ok = p.b_base_km(k0 + kr, z, off);
+        const u16* b0 = ok ? p.b_ptr() + off + n0 : reinterpret_cast<const u16*>(p.zero);
+        const u16* b1 = ok ? p.b_ptr() + p.b_plane() + off + n0 : reinterpret_cast<const u16*>(p.zero);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int ch = c0 + TP * i;
-        sb[i] = p.b_load_km(k0 + kr, n0 + (ch % V) * 8, ch / V, z);
+        for (int i = 0; i < NB; ++i) {
+          const int ch = c0 + TP * i;
+          sb[i] = ld16((ch / V ? b1 : b0) + (ch % V) * 8);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int ch = c0 + TP * i;
+          sb[i] = p.b_load_km(k0 + kr, n0 + (ch % V) * 8, ch / V, z);
+        }
       }
     }
   };
@@ -502,12 +564,20 @@ inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t st
 template <class P>
 inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0) {
   const int bk = igemm16_bk(P::A_KM);
-  if (bk == 32) {
-    launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
-  } else if (!P::A_KM && ctile > 0 && ctile % 64 == 0) {
-    if constexpr (!P::A_KM) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream);
+  if constexpr (P::A_KM) {
+    // pixel-major (wgrad) family: FAST when the chosen tile lies fully inside M x N (no channel tails)
+    Tile16 t = choose_tile16(M, N, gz);
+    const bool fast = (M % t.bm == 0) && (N % t.bn == 0);
+    if (bk == 32) {
+      if (fast) launch_igemm16_bk<P, 32, true>(p, M, N, gz, stream);
+      else launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
+    } else {
+      launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
+    }
   } else {
-    launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
+    if (bk == 32) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
+    else if (ctile > 0 && ctile % 64 == 0) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream);
+    else launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
   }
 }
 #endif  // __HIPCC__
