@@ -130,10 +130,19 @@ def _worker_gpu(rank, port, out_dir):
     opt = optim.Adam(vae.parameters(), lr=1e-4)
     fused = engine.FusedVAEStep(vae, opt, hi - lo, S, C, precision="f32")   # the collective is what is under test
     assert abs(opt.grad_scale - 1.0 / WORLD) < 1e-12
-    fused.forward_backward(x[lo:hi].cuda(), eps[lo:hi].cuda())
-    parallel.allreduce_flat_grads(opt.flat_grad)
-    grads = {n: q.grad.detach().cpu() / WORLD for n, q in vae.named_parameters()}
-    opt.step()
+    # fused.step() = fwd/bwd + two-bucket all-reduce (decoder slice overlapped with the encoder backward) + Adam;
+    # intercept the optimiser to read the reduced gradients before the update consumes them
+    grads = {}
+    real_step = opt.step
+
+    def spy():
+        torch.cuda.synchronize()
+        grads.update({n: q.grad.detach().cpu() / WORLD for n, q in vae.named_parameters()})
+        real_step()
+
+    opt.step = spy
+    assert fused.world == WORLD
+    fused.step(x[lo:hi].cuda(), eps[lo:hi].cuda())
     torch.cuda.synchronize()
     torch.save({"grads": grads, "params": {n: q.detach().cpu() for n, q in vae.named_parameters()}}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()

@@ -303,6 +303,9 @@ class FusedVAEStep:
                                             lib.vp_gemm_workspace_bytes(Z, 1024, B), lib.vp_gemm_workspace_bytes(B, 1024, Z)))
         wsn = ws_g1.numel() * 4
         bwd.add("vp_gemm_f32", P(cur), 1, F1, P(self.z), 1, Z, P(grad_of(dfc_lin.weight)), Z, None, F1, Z, B, 2, P(ws_g1), wsn)
+        # every decoder gradient is final here: the data-parallel step may start reducing that slice of the arena
+        self._bwd_dec = bwd
+        bwd = _Plan()
         dz = self._buf("g.dz", B, Z)
         bwd.add("vp_gemm_f32", P(cur), F1, 1, P(dfc_lin.weight), 1, Z, P(dz), Z, None, B, Z, F1, 1, P(ws_g1), wsn)
         dmu, dlv = self._buf("g.dmu", B, Z), self._buf("g.dlv", B, Z)
@@ -361,15 +364,18 @@ class FusedVAEStep:
         return n
 
     # ---- execution ---------------------------------------------------------------------------
-    def _launch_all(self, timers: Optional[dict] = None):
+    def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None):
         s = torch.cuda.current_stream().cuda_stream
         self._fwd.run(s, timers)
+        self._bwd_dec.run(s, timers)
+        if on_decoder_grads is not None:
+            on_decoder_grads()
         self._bwd_a.run(s, timers)
         self._dhb[0].add_(self._dhb[1])          # d hb = dgrad(mu head) + dgrad(logvar head)  (B x 1024)
         self._bwd_b.run(s, timers)
         torch.add(self.recon, self.kl_sum, out=self._loss_num)
 
-    def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None):
+    def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None):
         """Gradients of (BCE_sum + KL_sum)/B land in the optimiser's flat gradient arena.
         Returns (loss, recon, kl) as device scalars (no host sync).  ``timers`` =
         {"names": set of entry points, "events": []} brackets those launches with HIP events
@@ -378,10 +384,10 @@ class FusedVAEStep:
             self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
         self.x_nchw.copy_(x, non_blocking=True)
         self.eps.copy_(eps, non_blocking=True)
-        if self._graph is not None and timers is None:
+        if self._graph is not None and timers is None and on_decoder_grads is None:
             self._graph.replay()
         else:
-            self._launch_all(timers)
+            self._launch_all(timers, on_decoder_grads)
         # BatchNorm num_batches_tracked is advanced lazily in sync_counters()
         self._steps_since_sync = getattr(self, "_steps_since_sync", 0) + 1
         return self._loss_num / self.B, self.recon, self.kl_sum
@@ -394,10 +400,37 @@ class FusedVAEStep:
                 m.num_batches_tracked.add_(n)
             self._steps_since_sync = 0
 
-    def step(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None):
-        """One full training step: fwd + loss + bwd, ONE all-reduce of the gradient arena, fused update."""
-        out = self.forward_backward(x, eps, timers)
-        parallel.allreduce_flat_grads(self.opt.flat_grad, self.group)
+    def _decoder_slice_start(self) -> int:
+        """Arena offset of the first decoder parameter (encoder parameters precede it in ``vae.parameters()``)."""
+        dec_ids = {id(p) for p in self.vae.decoder.parameters()}
+        offs = [o for p, o in zip(self.opt.arena.params, self.opt.arena.offsets) if id(p) in dec_ids]
+        first = min(offs)
+        assert all(o >= first for o in offs) and all(
+            (id(p) in dec_ids) == (o >= first) for p, o in zip(self.opt.arena.params, self.opt.arena.offsets)), \
+            "decoder parameters must form the tail of the flat arena"
+        return first
+
+    def step(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, overlap: bool = True):
+        """One full training step: fwd + loss + bwd, SUM all-reduce of the flat gradient arena, fused update.
+
+        With several ranks the arena is reduced as two buckets of the same flat buffer: the decoder slice is
+        handed to RCCL as soon as the decoder's gradients are final (its all-reduce runs on the communicator's
+        stream underneath the rest of backward), the encoder slice after backward; the optimiser kernel waits
+        for both.  ``overlap=False`` issues one all-reduce of the whole arena after backward."""
+        if self.world > 1 and overlap:
+            g = self.opt.flat_grad
+            cut = self._decoder_slice_start()
+            works = []
+            out = self.forward_backward(
+                x, eps, timers,
+                on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)))
+            works.append(parallel.allreduce_flat_grads(g[:cut], self.group, async_op=True))
+            for w in works:
+                if w is not None:
+                    w.wait()
+        else:
+            out = self.forward_backward(x, eps, timers)
+            parallel.allreduce_flat_grads(self.opt.flat_grad, self.group)
         self.opt.step()
         return out
 
