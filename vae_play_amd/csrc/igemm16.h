@@ -103,23 +103,26 @@ struct ProbF16 {
   // taps of one 64-channel chunk gather overlapping pixels back to back, so the re-reads hit the per-XCD L2
   // (tap-major order re-reads a pixel only after a full channel sweep -- far more than 4 MB per XCD -- and
   // every conv kernel then streamed its operands at the same ~10 TB/s regardless of tile shape).
+  template <int SH = 6>
   VP_HD void fast_tile(int k0, int ntap, int& tap, int& c0) const {
-    const int kt = k0 >> 6;
+    const int kt = k0 >> SH;
     const int cc = kt / ntap;            // scalar: k0 and ntap are workgroup-uniform
     tap = kt - cc * ntap;
-    c0 = cc << 6;
+    c0 = cc << SH;
   }
+  template <int SH = 6>
   VP_HD bool a_base(const ARow& r, int k0, const ZCtx&, size_t& off) const {
     int tap, c0;
-    fast_tile(k0, kTaps, tap, c0);
+    fast_tile<SH>(k0, kTaps, tap, c0);
     const int rr = div_small(tap, 5), qq = tap - rr * 5;
     const int h = r.h0 + rr, w_ = r.w0 + qq;
     off = (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c0;
     return r.valid && k0 < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
   }
+  template <int SH = 6>
   VP_HD bool b_base(const BRow& r, int k0, const ZCtx&, size_t& off) const {
     int tap, c0;
-    fast_tile(k0, kTaps, tap, c0);
+    fast_tile<SH>(k0, kTaps, tap, c0);
     off = (size_t)r.off + tap * g.Cb + c0;
     return r.valid && k0 < K;
   }
@@ -177,24 +180,27 @@ struct ProbT16 {
     const bool ok = r.valid && kt < z.k_end;
     return ld16(ok ? w + plane * w_plane + (size_t)r.off + tap * g.Cs + c : reinterpret_cast<const u16*>(zero));
   }
+  template <int SH = 6>
   VP_HD void fast_tile(int k0, int ntap, int& t, int& c0) const {   // channel-chunk major, tap minor (see ProbF16)
-    const int kt = k0 >> 6;
+    const int kt = k0 >> SH;
     const int cc = kt / ntap;
     t = kt - cc * ntap;
-    c0 = cc << 6;
+    c0 = cc << SH;
   }
+  template <int SH = 6>
   VP_HD bool a_base(const ARow& r, int k0, const ZCtx& z, size_t& off) const {
     int t, c0;
-    fast_tile(k0, z.th * z.tw, t, c0);
+    fast_tile<SH>(k0, z.th * z.tw, t, c0);
     const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
     const int d0 = g.stride == 2 ? 1 : 2;
     const int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
     off = (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c0;
     return r.valid && k0 < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
   }
+  template <int SH = 6>
   VP_HD bool b_base(const BRow& r, int k0, const ZCtx& z, size_t& off) const {
     int t, c0;
-    fast_tile(k0, z.th * z.tw, t, c0);
+    fast_tile<SH>(k0, z.th * z.tw, t, c0);
     const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
     const int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
     off = (size_t)r.off + tap * g.Cs + c0;
@@ -529,11 +535,180 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 }
 
 struct Tile16 { int bm, bn; };
+
 inline Tile16 choose_tile16(long M, long N, int gz) {
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
   if (M >= 128 && N >= 128 && blocks(128, 128) >= 384) return {128, 128};
   if (M >= 128 && N >= 64 && blocks(128, 64) >= 384) return {128, 64};
   return {64, 64};
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the gather/scatter families (FAST shapes: channel count a multiple of 32).
+// Staging with global loads + ds_write_b128 costs ~830 LDS cycles per 128x128x64 tile (the VGPR->LDS store
+// path moves ~79 B/clk/CU) against 1536 MFMA cycles, and needs two barriers per tile.  Here every 16-B
+// chunk goes HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write):
+//   * K-tile = 32 elements -> 64-B rows per bf16 plane, stored UNPADDED (an LDS-DMA wave-instruction writes
+//     1 KiB = 16 consecutive rows, destination = wave-uniform base + lane*16);
+//   * bank conflicts are removed by an XOR swizzle applied to the per-lane SOURCE address and again on the
+//     fragment read: physical chunk = logical chunk ^ ((row >> 2) & 3)  (rows r, r+4, r+8, r+12 share a
+//     64-B segment of the 256-B bank row; the XOR sends their equal logical chunks to 4 different slots);
+//   * two LDS buffers, ONE barrier per K-tile: DMA(t+1) is issued before the MFMAs of tile t and retired by
+//     s_waitcnt vmcnt(0) + barrier after them;
+//   * out-of-range rows / padding taps source the zero page, so there is no predication anywhere.
+// ---------------------------------------------------------------------------------------------------------
+template <class P, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm16_dma_kernel(const P p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(!P::A_KM && !P::B_KM, "DMA variant: k-contiguous operands only");
+  constexpr int BKT = 32;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;           // bytes per plane and buffer
+  constexpr int BUF = 2 * A_PLANE + 2 * B_PLANE;
+  constexpr int NIA = BM / 32, NIB = BN / 32;                    // DMA instructions per wave and tile
+  constexpr int NRA = (NIA + 1) / 2, NRB = (NIB + 1) / 2;        // distinct rows per lane (each feeds both planes)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* g_ptr;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  typename P::ZCtx z;
+  p.z_setup(blockIdx.z, z);
+
+  // DMA map: pair index pi = wave*NI + i; row block rb = pi >> 1 (16 rows), plane = pi & 1;
+  // lane -> row = rb*16 + lane/4, physical chunk = lane & 3
+  typename P::ARow ra[NRA];
+  typename P::BRow rb_[NRB];
+  int swa[NRA], swb[NRB];
+#pragma unroll
+  for (int j = 0; j < NRA; ++j) {
+    const int row = ((wave * NIA) / 2 + j) * 16 + (lane >> 2);
+    ra[j] = p.a_row(m0 + row, z);
+    swa[j] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;                // logical chunk -> element offset
+  }
+#pragma unroll
+  for (int j = 0; j < NRB; ++j) {
+    const int row = ((wave * NIB) / 2 + j) * 16 + (lane >> 2);
+    rb_[j] = p.b_row(n0 + row, z);
+    swb[j] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+  }
+  const u16* zsrc = reinterpret_cast<const u16*>(p.zero) + (lane & 3) * 8;
+
+  auto dma_tile = [&](int k0, int buf) {
+    unsigned char* base = lds + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < NRA; ++j) {
+      size_t off;
+      const bool ok = p.template a_base<5>(ra[j], k0, z, off);
+      const u16* s0 = ok ? p.a_ptr() + off + swa[j] : zsrc;
+      const u16* s1 = ok ? p.a_ptr() + p.a_plane() + off + swa[j] : zsrc;
+      const int rblk = (wave * NIA) / 2 + j;
+      __builtin_amdgcn_global_load_lds((g_ptr)s0, (lds_ptr)(base + rblk * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((g_ptr)s1, (lds_ptr)(base + A_PLANE + rblk * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {
+      size_t off;
+      const bool ok = p.template b_base<5>(rb_[j], k0, z, off);
+      const u16* s0 = ok ? p.b_ptr() + off + swb[j] : zsrc;
+      const u16* s1 = ok ? p.b_ptr() + p.b_plane() + off + swb[j] : zsrc;
+      const int rblk = (wave * NIB) / 2 + j;
+      __builtin_amdgcn_global_load_lds((g_ptr)s0, (lds_ptr)(base + 2 * A_PLANE + rblk * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((g_ptr)s1, (lds_ptr)(base + 2 * A_PLANE + B_PLANE + rblk * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int klen = z.k_end - z.k_begin;
+  const int nk = klen > 0 ? (klen + BKT - 1) / BKT : 0;
+  const int arow0 = wm * (BM / WM) + li;
+  const int brow0 = wn * (BN / WN) + li;
+  const int sw = (li >> 2) & 3;                                   // read-side swizzle: (row >> 2) & 3 of this lane's rows
+
+  if (nk > 0) {
+    dma_tile(z.k_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) dma_tile(z.k_begin + (kt + 1) * BKT, (kt + 1) & 1);
+    const unsigned char* A0 = lds + (kt & 1) * BUF;
+    const unsigned char* B0 = A0 + 2 * A_PLANE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int coff = ((2 * s + lh) ^ sw) * 16;
+      bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned char* q = A0 + (arow0 + 32 * i) * 64 + coff;
+        ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(q));
+        al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(q + A_PLANE));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned char* q = B0 + (brow0 + 32 * j) * 64 + coff;
+        bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(q));
+        bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(q + B_PLANE));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed
+    __syncthreads();                                    // every wave's pieces have; buffer kt&1 is free again
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + wm * (BM / WM) + 32 * i + row;
+        const int n = n0 + wn * (BN / WN) + 32 * j + li;
+        p.store(m, n, acc[i][j][r], z);
+      }
+}
+
+template <class P>
+inline void launch_igemm16_dma(const P& p, long M, long N, int gz, hipStream_t stream) {
+  Tile16 t = choose_tile16(M, N, gz);
+  dim3 block(256);
+  auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
+  if (t.bm == 128 && t.bn == 128) {
+    hipLaunchKernelGGL((igemm16_dma_kernel<P, 128, 128, 2, 2>), grid(128, 128), block, 0, stream, p);
+  } else if (t.bm == 128 && t.bn == 64) {
+    hipLaunchKernelGGL((igemm16_dma_kernel<P, 128, 64, 2, 2>), grid(128, 64), block, 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((igemm16_dma_kernel<P, 64, 64, 2, 2>), grid(64, 64), block, 0, stream, p);
+  }
+}
+
+// Opt-in (VP_IGEMM16_DMA=1): in this one-tile-ahead form the DMA variant measured 10-25 % slower than the
+// register-staged BK=64 kernel on every layer (profiles/r01_c_notes.md): a 32-deep tile is 768 MFMA cycles,
+// too short to cover the DMA latency; it needs counted vmcnt + raw barriers + a third buffer to pay off.
+inline int igemm16_use_dma() {
+  static int v = [] { const char* e = getenv("VP_IGEMM16_DMA"); return e ? atoi(e) : 0; }();
+  return v;
 }
 
 // K-tile depth: 64 for the gather/scatter families (half the barriers per MFMA), 32 for the weight
@@ -575,7 +750,8 @@ inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t strea
       launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
     }
   } else {
-    if (bk == 32) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
+    if (ctile > 0 && ctile % 32 == 0 && igemm16_use_dma()) launch_igemm16_dma<P>(p, M, N, gz, stream);
+    else if (bk == 32) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
     else if (ctile > 0 && ctile % 64 == 0) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream);
     else launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
   }
