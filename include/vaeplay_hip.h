@@ -64,6 +64,20 @@ int vp_conv5_wgrad_f32(const float* big, const float* small, float* dw_ref,
                        int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
                        void* ws, size_t ws_bytes, vp_stream stream);
 
+/* ---- k x k generalisation (ks = 1, 3 or 5, padding (ks-1)/2, stride 1 or 2) -------------------------------------
+ * The conv/norm/act vocabulary of models/blocks.py:5-34 (nn.Conv2d(k, stride, padding=(k-1)//2)); same three families.
+ * The big side is passed explicitly (Hb, Wb) so odd sizes work: Hs = floor((Hb + 2*pad - ks)/stride) + 1.
+ * Weights: reference tensor W[Csmall][Cbig][ks][ks]; packed p0 = [Csmall][ks*ks][Cbig], p1 = [Cbig][ks*ks][Csmall]. */
+int vp_pack_w_f32(const float* w_ref, float* p0, float* p1, int Csmall, int Cbig, int ks, vp_stream stream);
+int vp_conv_gather_f32(const float* big, const float* w_p0, const float* bias, float* small_out,
+                       int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride, int act, vp_stream stream);
+int vp_conv_scatter_f32(const float* small, const float* w_p1, float* big_out,
+                        int B, int Hs, int Ws, int Hb, int Wb, int Csmall, int Cbig, int ks, int stride, vp_stream stream);
+size_t vp_conv_wgrad_workspace_bytes(int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride);
+int vp_conv_wgrad_f32(const float* big, const float* small, float* dw_ref,
+                      int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride,
+                      void* ws, size_t ws_bytes, vp_stream stream);
+
 /* ---- split-bf16 ("bf16x3") variants of the three families ------------------------------------------
  * A "split" tensor stores an fp32 tensor of n elements as two bf16 planes in one buffer of 2*n
  * uint16: hi = bf16(x) at [0,n), lo = bf16(x - hi) at [n,2n).  The contraction issues three
@@ -130,6 +144,15 @@ int vp_bn_act_bwd_f32(const float* x, const float* dy, const float* mean, const 
 int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream);
 /* dx = dy * act'(.) evaluated from the OUTPUT y (relu/lrelu/tanh/sigmoid); dx may alias dy */
 int vp_act_bwd_from_y_f32(const float* y, const float* dy, float* dx, size_t n, int act, float slope, vp_stream stream);
+
+/* ---- models/blocks.py helpers (NHWC) ------------------------------------------------------------------------- */
+/* F.interpolate(scale_factor=2, mode='bilinear') of blocks.Up (models/blocks.py:145): y[B,2H,2W,C]; and its adjoint */
+int vp_upsample2x_bilinear_fwd_f32(const float* x, float* y, int B, int H, int W, int C, vp_stream stream);
+int vp_upsample2x_bilinear_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, vp_stream stream);
+/* AddCoords (models/blocks.py:97-112): out[B,H,W,C+2] = cat(x, column index, row index); normalize as if_normalize */
+int vp_add_coords_f32(const float* x, float* out, int B, int H, int W, int C, int normalize, vp_stream stream);
+/* out[p][0..Cout) = in[p][0..Cout): gradient of AddCoords / channel slice */
+int vp_slice_channels_f32(const float* in, float* out, size_t npix, int Cin, int Cout, vp_stream stream);
 
 /* ---- latent: reparameterisation + KL -------------------------------------------------------- */
 /* z = eps*exp(0.5*logvar) + mu   (models/networks.py:228-231);

@@ -228,6 +228,82 @@ def init_fixture(nets):
     return out
 
 
+def _params_of(mod):
+    return {k: v.detach().clone() for k, v in mod.state_dict().items()}
+
+
+def _run_block(mod, oracle_fn, x, seed, tag):
+    """Forward + backward of a reference blocks module and of the oracle restatement on the same numbers;
+    returns a fixture with full tensors."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for q in mod.parameters():          # non-trivial affine parameters
+            q.copy_(q + 0.1 * torch.randn(q.shape, generator=g))
+    p0 = _params_of(mod)
+    mod.train()
+    xr = x.clone().requires_grad_(True)
+    y = mod(xr)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    p = {k: v.clone() for k, v in p0.items()}
+    for k in p:
+        if p[k].dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            p[k].requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    yo = oracle_fn(p, xo)
+    yo.backward(gy)
+    bit_equal(yo.detach(), y.detach(), tag + " y")
+    bit_equal(xo.grad, xr.grad, tag + " dx")
+    fx = {"x": np_(x), "y": np_(y), "gy": np_(gy), "dx": np_(xr.grad)}
+    named = dict(mod.named_parameters())
+    for k, v in p0.items():
+        fx["param/" + k] = np_(v)
+    for k, q in named.items():
+        bit_equal(p[k].grad, q.grad, tag + " grad " + k)
+        fx["grad/" + k] = np_(q.grad)
+    for k, v in mod.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            bit_equal(p[k], v, tag + " " + k)
+            fx["after/" + k] = np_(v)
+    return fx
+
+
+def blocks_fixtures(blocks, save):
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 6, 10, 10, generator=g)
+    i = 0
+    for bn in (None, "batch", "instance"):
+        for act in ("relu", "lrelu", "tanh", None):
+            for ks, stride in ((3, 1), (3, 2)) if i % 2 == 0 else ((1, 1), (5, 2)):
+                torch.manual_seed(100 + i)
+                mod = blocks.Conv2d(6, 8, ks, stride, bn, act)
+                fx = _run_block(mod, lambda p, xx: O.blocks_conv2d(p, "", xx, ks, stride, bn, act, True), x, 200 + i,
+                                f"blocks.Conv2d k{ks} s{stride} {bn} {act}")
+                fx["meta"] = np.array([6, 8, ks, stride])
+                save(f"blocks_conv2d_k{ks}s{stride}_{bn}_{act}", fx)
+            i += 1
+    torch.manual_seed(300)
+    mod = blocks.Up(6, 4, True)
+    save("blocks_up_coord", _run_block(mod, lambda p, xx: O.blocks_up(p, "", xx, True, True), x, 301, "blocks.Up"))
+    torch.manual_seed(310)
+    mod = blocks.Up(6, 8, False)
+    save("blocks_up", _run_block(mod, lambda p, xx: O.blocks_up(p, "", xx, False, True), torch.randn(2, 6, 7, 9, generator=g), 311, "blocks.Up odd"))
+    torch.manual_seed(320)
+    mod = blocks.Down(6, 8, 3, True)
+    save("blocks_down_coord", _run_block(mod, lambda p, xx: O.blocks_down(p, "", xx, 3, True, True), x, 321, "blocks.Down"))
+    for act in ("relu", "lrelu", "tanh", None):
+        torch.manual_seed(330)
+        mod = blocks.Linear(12, 7, True, act)
+        xl = torch.randn(5, 12, generator=g)
+        save(f"blocks_linear_{act}", _run_block(mod, lambda p, xx: O.blocks_linear(p, "", xx, act), xl, 331, f"blocks.Linear {act}"))
+    for norm in (False, True):
+        ac = blocks.AddCoords(norm)
+        xa = torch.randn(2, 3, 5, 7, generator=g)
+        ya = ac(xa)
+        bit_equal(O.blocks_add_coords(xa, norm), ya, "AddCoords")
+        save(f"blocks_addcoords_{int(norm)}", {"x": np_(xa), "y": np_(ya)})
+
+
 def main():
     nets, blocks = import_reference()
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -238,6 +314,7 @@ def main():
         np.savez_compressed(path, **fx)
         print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
+    blocks_fixtures(blocks, save)
     save("latent", latent_fixture(nets))
     save("init", init_fixture(nets))
     save("encblock_4to8", block_fixture(nets, "enc", 4, 8, 2, 16, 11))

@@ -273,3 +273,63 @@ def checksum(t: torch.Tensor) -> Dict[str, torch.Tensor]:
     idx = sample_indices(f.numel())
     return {"sum": f.sum().reshape(1), "l2": f.pow(2).sum().sqrt().reshape(1),
             "samples": t.detach().flatten()[idx].double()}
+
+
+# --------------------------------------------------------------------------
+# models/blocks.py vocabulary: functional restatement over a params dict whose keys are the
+# reference state_dict keys ("conv.0.weight", "conv.1.running_mean", ...)
+# --------------------------------------------------------------------------
+def _blocks_act(y: torch.Tensor, act: Optional[str], lrelu_slope: float) -> torch.Tensor:
+    if act == "relu":
+        return F.relu(y)
+    if act == "lrelu":
+        return F.leaky_relu(y, lrelu_slope)
+    if act == "tanh":
+        return torch.tanh(y)
+    return y
+
+
+def blocks_conv2d(p: Params, prefix: str, x: torch.Tensor, kernel_size: int, stride: int = 1, bn: Optional[str] = None,
+                  act: Optional[str] = "relu", training: bool = True) -> torch.Tensor:
+    """models/blocks.py:5-34: conv(pad=(k-1)//2, bias iff bn is None) -> {BatchNorm2d | InstanceNorm2d | -} -> act."""
+    y = F.conv2d(x, p[prefix + "conv.0.weight"], p.get(prefix + "conv.0.bias"), stride=stride, padding=(kernel_size - 1) // 2)
+    if bn == "batch":
+        y = F.batch_norm(y, p[prefix + "conv.1.running_mean"], p[prefix + "conv.1.running_var"], p[prefix + "conv.1.weight"],
+                         p[prefix + "conv.1.bias"], training, 0.1, 1e-5)
+        if training:
+            p[prefix + "conv.1.num_batches_tracked"] += 1
+    elif bn == "instance":
+        y = F.instance_norm(y, eps=1e-5)
+    return _blocks_act(y, act, 0.02)
+
+
+def blocks_linear(p: Params, prefix: str, x: torch.Tensor, act: Optional[str] = "relu") -> torch.Tensor:
+    """models/blocks.py:36-50 (LeakyReLU slope 0.2)."""
+    return _blocks_act(F.linear(x, p[prefix + "fc.0.weight"], p.get(prefix + "fc.0.bias")), act, 0.2)
+
+
+def blocks_add_coords(x: torch.Tensor, if_normalize: bool = False) -> torch.Tensor:
+    """models/blocks.py:97-112: append column-index and row-index channels."""
+    b, c, h, w = x.shape
+    ci = torch.arange(0, w, dtype=x.dtype).reshape(1, 1, 1, -1).repeat(b, 1, h, 1)
+    cj = torch.arange(0, h, dtype=x.dtype).reshape(1, 1, -1, 1).repeat(b, 1, 1, w)
+    if if_normalize:
+        ci = (ci / w - 0.5) / 0.5
+        cj = (cj / h - 0.5) / 0.5
+    return torch.cat([x, ci, cj], dim=1)
+
+
+def blocks_down(p: Params, prefix: str, x: torch.Tensor, kernel_size: int, if_add_coord: bool = False, training: bool = True):
+    """models/blocks.py:114-127."""
+    if if_add_coord:
+        x = blocks_add_coords(x)
+    return blocks_conv2d(p, prefix + "conv.", x, kernel_size, 2, None, "relu", training)
+
+
+def blocks_up(p: Params, prefix: str, x: torch.Tensor, if_add_coord: bool = False, training: bool = True):
+    """models/blocks.py:129-146: (AddCoords) -> 2 x [conv3 + BN + ReLU] -> bilinear x2 (align_corners=False)."""
+    if if_add_coord:
+        x = blocks_add_coords(x)
+    x = blocks_conv2d(p, prefix + "conv.0.", x, 3, 1, "batch", "relu", training)
+    x = blocks_conv2d(p, prefix + "conv.1.", x, 3, 1, "batch", "relu", training)
+    return F.interpolate(x, scale_factor=2, mode="bilinear")

@@ -71,10 +71,18 @@ static void emulate(const P& p, int M, int N, int gz) {
 }
 
 extern "C" {
+int emul_conv_gather(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int);
+int emul_conv_scatter(const float*, const float*, float*, int, int, int, int, int, int, int, int, int);
+int emul_conv_wgrad(const float*, const float*, float*, int, int, int, int, int, int, int, int, int, int);
 
 int emul_conv5_gather(const float* big, const float* wp0, const float* bias, float* out, int B, int Hs, int Ws,
                       int Cb, int Cs, int stride, int act) {
-  ConvGeom g = make_geom(B, Hs, Ws, Cs, Cb, stride);
+  return emul_conv_gather(big, wp0, bias, out, B, Hs, Ws, Hs * stride, Ws * stride, Cb, Cs, 5, stride, act);
+}
+
+int emul_conv_gather(const float* big, const float* wp0, const float* bias, float* out, int B, int Hs, int Ws, int Hb, int Wb,
+                     int Cb, int Cs, int ks, int stride, int act) {
+  ConvGeom g = make_geom(B, Hs, Ws, Cs, Cb, stride, ks, Hb, Wb);
   ProbF p = make_probF(big, wp0, bias, out, g, act);
   emulate(p, p.M, p.N, 1);
   return 0;
@@ -82,7 +90,12 @@ int emul_conv5_gather(const float* big, const float* wp0, const float* bias, flo
 
 int emul_conv5_scatter(const float* small, const float* wp1, float* out, int B, int Hs, int Ws, int Cs, int Cb,
                        int stride) {
-  ConvGeom g = make_geom(B, Hs, Ws, Cs, Cb, stride);
+  return emul_conv_scatter(small, wp1, out, B, Hs, Ws, Hs * stride, Ws * stride, Cs, Cb, 5, stride);
+}
+
+int emul_conv_scatter(const float* small, const float* wp1, float* out, int B, int Hs, int Ws, int Hb, int Wb, int Cs, int Cb,
+                      int ks, int stride) {
+  ConvGeom g = make_geom(B, Hs, Ws, Cs, Cb, stride, ks, Hb, Wb);
   ProbT p = make_probT(small, wp1, out, g);
   emulate(p, p.M, p.N, stride * stride);
   return 0;
@@ -91,18 +104,23 @@ int emul_conv5_scatter(const float* small, const float* wp1, float* out, int B, 
 // returns nsplit used; slab must hold wgrad_slab_floats
 int emul_conv5_wgrad(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Cb, int Cs,
                      int stride, int force_split) {
-  ConvGeom g = make_geom(B, Hs, Ws, Cs, Cb, stride);
+  return emul_conv_wgrad(big, small, dw_ref, B, Hs, Ws, Hs * stride, Ws * stride, Cb, Cs, 5, stride, force_split);
+}
+
+int emul_conv_wgrad(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cb, int Cs,
+                    int ks, int stride, int force_split) {
+  ConvGeom g = make_geom(B, Hs, Ws, Cs, Cb, stride, ks, Hb, Wb);
   int ns = force_split > 0 ? force_split : wgrad_nsplit(g);
   std::vector<float> slab(wgrad_slab_floats(g, ns), 0.f);
   ProbW p = make_probW(big, small, slab.data(), g, ns);
-  emulate(p, p.M, p.N, kTaps * ns);
+  emulate(p, p.M, p.N, g.nt * ns);
   // reduce: dw_ref[cs][cb][tap] = sum_split slab[split][tap][cs][cb]
   for (int cs = 0; cs < Cs; ++cs)
     for (int cb = 0; cb < Cb; ++cb)
-      for (int t = 0; t < kTaps; ++t) {
+      for (int t = 0; t < g.nt; ++t) {
         double s = 0;
-        for (int sp = 0; sp < ns; ++sp) s += slab[(((size_t)sp * kTaps + t) * Cs + cs) * Cb + cb];
-        dw_ref[((size_t)cs * Cb + cb) * kTaps + t] = (float)s;
+        for (int sp = 0; sp < ns; ++sp) s += slab[(((size_t)sp * g.nt + t) * Cs + cs) * Cb + cb];
+        dw_ref[((size_t)cs * Cb + cb) * g.nt + t] = (float)s;
       }
   return ns;
 }

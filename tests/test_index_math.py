@@ -150,3 +150,37 @@ def test_linear_gemm_forms(emul, M, N, K, split):
     dW = torch.empty(N, K)   # dW[n][k] = sum_m dy[m][n] x[m][k]  -> contraction over m
     emul.emul_gemm(ptr(dy), 1, N, ptr(x), 1, K, ptr(dW), K, None, N, K, M, 2, split)
     close(dW, dy.t() @ x, 1e-5)
+
+
+# ---- k x k generalisation (models/blocks.py Conv2d: kernel 1/3/5, padding (k-1)//2, stride 1/2, odd sizes) ----
+KCASES = [  # (B, Hb, Cb, Cs, ks, stride)
+    (2, 8, 4, 8, 3, 1), (2, 8, 4, 8, 3, 2), (1, 9, 5, 6, 3, 2), (2, 7, 3, 4, 3, 1), (2, 8, 8, 4, 1, 1),
+    (2, 8, 6, 4, 1, 2), (1, 11, 4, 4, 5, 2), (2, 10, 34, 8, 3, 1), (1, 6, 8, 1, 3, 1),
+]
+
+
+@pytest.mark.parametrize("B,Hb,Cb,Cs,ks,stride", KCASES)
+def test_kxk_families_match_torch(emul, B, Hb, Cb, Cs, ks, stride):
+    g = torch.Generator().manual_seed(ks * 100 + Hb + Cb)
+    pad = (ks - 1) // 2
+    Hs = (Hb + 2 * pad - ks) // stride + 1
+    big = torch.randn(B, Cb, Hb, Hb, generator=g)
+    w = torch.randn(Cs, Cb, ks, ks, generator=g, requires_grad=True)
+    bias = torch.randn(Cs, generator=g)
+    bigr = big.clone().requires_grad_(True)
+    y = F.conv2d(bigr, w, bias, stride=stride, padding=pad)
+    assert y.shape[-1] == Hs
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    wp0 = w.detach().permute(0, 2, 3, 1).contiguous()
+    wp1 = w.detach().permute(1, 2, 3, 0).contiguous()
+    out = torch.empty(B, Hs, Hs, Cs)
+    emul.emul_conv_gather(ptr(nhwc(big)), ptr(wp0), ptr(bias), ptr(out), B, Hs, Hs, Hb, Hb, Cb, Cs, ks, stride, 0)
+    close(out, nhwc(y.detach()))
+    dx = torch.full((B, Hb, Hb, Cb), float("nan"))
+    emul.emul_conv_scatter(ptr(nhwc(gy)), ptr(wp1), ptr(dx), B, Hs, Hs, Hb, Hb, Cs, Cb, ks, stride)
+    assert not torch.isnan(dx).any(), "some input-gradient pixels never written"
+    close(dx, nhwc(bigr.grad))
+    dw = torch.empty(Cs, Cb, ks, ks)
+    emul.emul_conv_wgrad(ptr(nhwc(big)), ptr(nhwc(gy)), ptr(dw), B, Hs, Hs, Hb, Hb, Cb, Cs, ks, stride, 0)
+    close(dw, w.grad)

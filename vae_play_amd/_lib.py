@@ -26,6 +26,11 @@ SIGNATURES = {
     "vp_conv5_scatter_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vp_conv5_wgrad_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "vp_pack_w_f32": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "vp_conv_gather_f32": (c_int, [P, P, P, P] + [c_int] * 10 + [P]),
+    "vp_conv_scatter_f32": (c_int, [P, P, P] + [c_int] * 9 + [P]),
+    "vp_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 9),
+    "vp_conv_wgrad_f32": (c_int, [P, P, P] + [c_int] * 9 + [P, c_size_t, P]),
     "vp_split_f32": (c_int, [P, P, c_size_t, P]),
     "vp_pack_w5_split": (c_int, [P, P, P, c_int, c_int, P]),
     "vp_conv5_gather_bf16x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -47,6 +52,10 @@ SIGNATURES = {
     "vp_bn_act_bwd_f32": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, c_size_t, P]),
     "vp_act_fwd_f32": (c_int, [P, P, c_size_t, c_int, c_float, P]),
     "vp_act_bwd_from_y_f32": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
+    "vp_upsample2x_bilinear_fwd_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "vp_upsample2x_bilinear_bwd_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "vp_add_coords_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_slice_channels_f32": (c_int, [P, P, c_size_t, c_int, c_int, P]),
     "vp_latent_fwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "vp_latent_bwd_f32": (c_int, [P, P, P, P, P, c_float, P, P, c_int, c_int, P]),
     "vp_reduce_workspace_bytes": (c_size_t, [c_size_t]),

@@ -28,25 +28,25 @@ __global__ void split_kernel(const float* __restrict__ x, u16_t* __restrict__ ou
 // CsP >= Cs: MODE 1 may zero-pad the small-channel (inner) dimension of p1 to CsP (edge layers on the bf16x3 path).
 template <int MODE, bool SPLIT>
 __global__ void __launch_bounds__(256) pack_w5_tiled_kernel(const float* __restrict__ w, void* __restrict__ outv, int Cs, int Cb,
-                                                            int CsP) {
+                                                            int CsP, int nt) {
   __shared__ float tile[64][kTaps + 1];
-  const size_t n = (size_t)(MODE == 1 ? CsP : Cs) * Cb * kTaps;
+  const size_t n = (size_t)(MODE == 1 ? CsP : Cs) * Cb * nt;
   const int fixed = blockIdx.x, j0 = blockIdx.y * 64;
   const int lim = (MODE == 0 ? Cb : Cs) - j0;           // valid entries of the 64-wide tile
   const int lim_out = (MODE == 0 ? Cb : CsP) - j0;      // entries written (zeros beyond lim)
-  for (int idx = threadIdx.x; idx < 64 * kTaps; idx += 256) {
-    const int j = idx / kTaps, t = idx - j * kTaps;
+  for (int idx = threadIdx.x; idx < 64 * nt; idx += 256) {
+    const int j = idx / nt, t = idx - j * nt;
     if (j < lim) {
-      const size_t src = MODE == 0 ? ((size_t)fixed * Cb + j0 + j) * kTaps + t : ((size_t)(j0 + j) * Cb + fixed) * kTaps + t;
+      const size_t src = MODE == 0 ? ((size_t)fixed * Cb + j0 + j) * nt + t : ((size_t)(j0 + j) * Cb + fixed) * nt + t;
       tile[j][t] = w[src];
     }
   }
   __syncthreads();
   const int inner = MODE == 0 ? Cb : CsP;
-  for (int idx = threadIdx.x; idx < 64 * kTaps; idx += 256) {
+  for (int idx = threadIdx.x; idx < 64 * nt; idx += 256) {
     const int t = idx >> 6, j = idx & 63;
     if (j < lim_out) {
-      const size_t o = ((size_t)fixed * kTaps + t) * inner + j0 + j;
+      const size_t o = ((size_t)fixed * nt + t) * inner + j0 + j;
       const float v = j < lim ? tile[j][t] : 0.f;
       if constexpr (SPLIT) {
         u16_t h, l;
@@ -61,15 +61,16 @@ __global__ void __launch_bounds__(256) pack_w5_tiled_kernel(const float* __restr
 }
 
 template <bool SPLIT>
-static int pack_w5_launch(const float* w, void* p0, void* p1, int Cs, int Cb, hipStream_t s, const char* what, int CsP = 0) {
+static int pack_w5_launch(const float* w, void* p0, void* p1, int Cs, int Cb, hipStream_t s, const char* what, int CsP = 0,
+                          int nt = kTaps) {
   if (CsP < Cs) CsP = Cs;
-  if (p0) hipLaunchKernelGGL((pack_w5_tiled_kernel<0, SPLIT>), dim3(Cs, (Cb + 63) / 64), dim3(256), 0, s, w, p0, Cs, Cb, Cs);
-  if (p1) hipLaunchKernelGGL((pack_w5_tiled_kernel<1, SPLIT>), dim3(Cb, (CsP + 63) / 64), dim3(256), 0, s, w, p1, Cs, Cb, CsP);
+  if (p0) hipLaunchKernelGGL((pack_w5_tiled_kernel<0, SPLIT>), dim3(Cs, (Cb + 63) / 64), dim3(256), 0, s, w, p0, Cs, Cb, Cs, nt);
+  if (p1) hipLaunchKernelGGL((pack_w5_tiled_kernel<1, SPLIT>), dim3(Cb, (CsP + 63) / 64), dim3(256), 0, s, w, p1, Cs, Cb, CsP, nt);
   return check_launch(what);
 }
 
-int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hipStream_t s) {
-  return pack_w5_launch<false>(w, p0, p1, Cs, Cb, s, "vp_pack_w5_f32");
+int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hipStream_t s, int nt) {
+  return pack_w5_launch<false>(w, p0, p1, Cs, Cb, s, "vp_pack_w_f32", 0, nt);
 }
 
 }  // namespace vp

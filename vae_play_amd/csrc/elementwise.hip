@@ -175,6 +175,88 @@ __global__ void bce_sigmoid_bwd_pad_kernel(const float* __restrict__ p, const fl
   }
 }
 
+// ---- models/blocks.py helpers (NHWC) -----------------------------------------------------------------------
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False): src = max((o + 0.5)/2 - 0.5, 0)
+__device__ __forceinline__ void bilin_src(int o, int in_size, int& i0, int& i1, float& lam) {
+  float src = (o + 0.5f) * 0.5f - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + 1 < in_size ? i0 + 1 : in_size - 1;
+  lam = src - (float)i0;
+}
+
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const size_t n = (size_t)B * Ho * Wo * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int ow = (int)(r % Wo); r /= Wo;
+    const int oh = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    int h0, h1, w0, w1; float lh, lw;
+    bilin_src(oh, H, h0, h1, lh);
+    bilin_src(ow, W, w0, w1, lw);
+    const float* xb = x + (size_t)b * H * W * C + c;
+    const float v00 = xb[((size_t)h0 * W + w0) * C], v01 = xb[((size_t)h0 * W + w1) * C];
+    const float v10 = xb[((size_t)h1 * W + w0) * C], v11 = xb[((size_t)h1 * W + w1) * C];
+    y[i] = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+  }
+}
+
+// gather form of the adjoint (no atomics): dx[h][w] = sum over the <= 5x5 output pixels whose stencil touches (h, w)
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const size_t n = (size_t)B * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int b = (int)(r / H);
+    const float* db = dy + (size_t)b * Ho * Wo * C + c;
+    float acc = 0.f;
+    for (int oh = max(0, 2 * h - 2); oh <= min(Ho - 1, 2 * h + 2); ++oh) {
+      int h0, h1; float lh;
+      bilin_src(oh, H, h0, h1, lh);
+      const float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+      if (wh == 0.f) continue;
+      for (int ow = max(0, 2 * w - 2); ow <= min(Wo - 1, 2 * w + 2); ++ow) {
+        int w0, w1; float lw;
+        bilin_src(ow, W, w0, w1, lw);
+        const float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+        if (ww != 0.f) acc += wh * ww * db[((size_t)oh * Wo + ow) * C];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// AddCoords (models/blocks.py:97-112): out[..., :C] = x, out[..., C] = column index, out[..., C+1] = row index
+__global__ void add_coords_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C, int normalize) {
+  const int Co = C + 2;
+  const size_t n = (size_t)B * H * W * Co;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Co);
+    const size_t pix = i / Co;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H);
+    float v;
+    if (c < C) v = x[pix * C + c];
+    else if (c == C) v = normalize ? ((float)w / (float)W - 0.5f) / 0.5f : (float)w;
+    else v = normalize ? ((float)h / (float)H - 0.5f) / 0.5f : (float)h;
+    out[i] = v;
+  }
+}
+
+// out[p][c] = in[p][c] for c < Cout (the gradient of AddCoords / a channel slice)
+__global__ void slice_channels_kernel(const float* __restrict__ in, float* __restrict__ out, size_t npix, int Cin, int Cout) {
+  const size_t n = npix * Cout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / Cout;
+    out[i] = in[pix * Cin + (i - pix * Cout)];
+  }
+}
+
 // torch.optim.Adam (single-tensor form): m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g;
 // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -299,6 +381,30 @@ int vp_bce_sigmoid_bwd_pad_split_f32(const float* p, const float* t, float gscal
   hipLaunchKernelGGL(bce_sigmoid_bwd_pad_kernel, dim3(grid_for(npix * Cpad, 256)), dim3(256), 0, (hipStream_t)stream, p, t, gscale,
                      dlogit, (u16_t*)dlogit_split, npix, C, Cpad);
   return check_launch("vp_bce_sigmoid_bwd_pad_split_f32");
+}
+
+int vp_upsample2x_bilinear_fwd_f32(const float* x, float* y, int B, int H, int W, int C, vp_stream stream) {
+  VP_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "vp_upsample2x_bilinear_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((size_t)B * 4 * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C);
+  return check_launch("vp_upsample2x_bilinear_fwd_f32");
+}
+
+int vp_upsample2x_bilinear_bwd_f32(const float* dy, float* dx, int B, int H, int W, int C, vp_stream stream) {
+  VP_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "vp_upsample2x_bilinear_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((size_t)B * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C);
+  return check_launch("vp_upsample2x_bilinear_bwd_f32");
+}
+
+int vp_add_coords_f32(const float* x, float* out, int B, int H, int W, int C, int normalize, vp_stream stream) {
+  VP_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0, "vp_add_coords_f32: bad arguments");
+  hipLaunchKernelGGL(add_coords_kernel, dim3(grid_for((size_t)B * H * W * (C + 2), 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W, C, normalize);
+  return check_launch("vp_add_coords_f32");
+}
+
+int vp_slice_channels_f32(const float* in, float* out, size_t npix, int Cin, int Cout, vp_stream stream) {
+  VP_REQUIRE(in && out && npix > 0 && Cout > 0 && Cout <= Cin, "vp_slice_channels_f32: bad arguments");
+  hipLaunchKernelGGL(slice_channels_kernel, dim3(grid_for(npix * Cout, 256)), dim3(256), 0, (hipStream_t)stream, in, out, npix, Cin, Cout);
+  return check_launch("vp_slice_channels_f32");
 }
 
 int vp_adam_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,

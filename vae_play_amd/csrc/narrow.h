@@ -9,6 +9,6 @@ int narrow_gather_launch(const float* big, const float* w_p0, const float* bias,
 int narrow_wgrad_kind(const ConvGeom& g);
 size_t narrow_wgrad_ws_floats(const ConvGeom& g);
 int narrow_wgrad_launch(const float* big, const float* small, float* dw_ref, const ConvGeom& g, float* ws, hipStream_t s);
-int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hipStream_t s);
-int slab_reduce_launch(const float* slab, float* dw_ref, int Cs, int Cb, int nsplit, hipStream_t s);
+int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hipStream_t s, int nt = kTaps);
+int slab_reduce_launch(const float* slab, float* dw_ref, int Cs, int Cb, int nsplit, hipStream_t s, int nt = kTaps);
 }  // namespace vp

@@ -238,9 +238,9 @@ __global__ void __launch_bounds__(256) wgrad_narrow_big_kernel(const float* __re
 
 // dw_ref[cs][cb][tap] = sum_split slab[split][tap][cs][cb]; 64 outputs x 4 split-lanes per workgroup.
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cs, int Cb,
-                                                          int nsplit) {
+                                                          int nsplit, int nt) {
   __shared__ float red[4][64];
-  const size_t per = (size_t)kTaps * Cs * Cb;
+  const size_t per = (size_t)nt * Cs * Cb;
   const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int sl = threadIdx.x >> 6;
   float s = 0.f;
@@ -253,13 +253,13 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
     const int cb = (int)(i % Cb);
     const size_t r = i / Cb;
     const int cs = (int)(r % Cs), t = (int)(r / Cs);
-    dw[((size_t)cs * Cb + cb) * kTaps + t] = v;
+    dw[((size_t)cs * Cb + cb) * nt + t] = v;
   }
 }
 
 // ---- host dispatch ------------------------------------------------------------------------------
 bool narrow_gather_applicable(const ConvGeom& g, int act) {
-  return g.stride == 1 && (g.Cs == 1 || g.Cs == 3) && g.Cb % 16 == 0 && (act == ACT_NONE || act == ACT_SIGMOID);
+  return g.ks == 5 && g.Hb == g.Hs && g.Wb == g.Ws && g.stride == 1 && (g.Cs == 1 || g.Cs == 3) && g.Cb % 16 == 0 && (act == ACT_NONE || act == ACT_SIGMOID);
 }
 
 int narrow_gather_launch(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g, int act,
@@ -281,6 +281,7 @@ static int narrow_rows_per_block(const ConvGeom& g) {
 }
 
 int narrow_wgrad_kind(const ConvGeom& g) {
+  if (g.ks != 5 || g.Hb != g.Hs * g.stride || g.Wb != g.Ws * g.stride) return 0;
   if (g.stride == 1 && (g.Cs == 1 || g.Cs == 3) && g.Cb % 64 == 0) return 1;   // narrow small side
   if ((g.Cb == 1 || g.Cb == 3) && g.Cs % 64 == 0) return 2;                     // narrow big side
   return 0;
@@ -317,13 +318,13 @@ int narrow_wgrad_launch(const float* big, const float* small, float* dw_ref, con
   int rc = check_launch("wgrad_narrow");
   if (rc) return rc;
   const size_t per = (size_t)kTaps * g.Cs * g.Cb;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, (const float*)ws, dw_ref, g.Cs, g.Cb, nblk);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, (const float*)ws, dw_ref, g.Cs, g.Cb, nblk, kTaps);
   return check_launch("slab_reduce");
 }
 
-int slab_reduce_launch(const float* slab, float* dw_ref, int Cs, int Cb, int nsplit, hipStream_t s) {
-  const size_t per = (size_t)kTaps * Cs * Cb;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit);
+int slab_reduce_launch(const float* slab, float* dw_ref, int Cs, int Cb, int nsplit, hipStream_t s, int nt) {
+  const size_t per = (size_t)nt * Cs * Cb;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);
   return check_launch("slab_reduce");
 }
 

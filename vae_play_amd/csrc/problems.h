@@ -96,6 +96,7 @@ VP_HD int div_small(int t, int tw) {
 
 struct ConvGeom {
   int B, Hs, Ws, Hb, Wb, Cs, Cb, stride;
+  int ks, pad, nt;             // kernel size (1, 3 or 5), padding (ks-1)/2, taps ks*ks
   FastDiv dHW, dW, dCs, dCb;   // divisors Hs*Ws, Ws, Cs, Cb
 };
 
@@ -130,14 +131,14 @@ struct ProbF {
     int hs = (int)g.dW.div((uint32_t)rem);
     int ws = rem - hs * g.Ws;
     r.pix_base = b * g.Hb * g.Wb;
-    r.h0 = g.stride * hs - 2;
-    r.w0 = g.stride * ws - 2;
+    r.h0 = g.stride * hs - g.pad;
+    r.w0 = g.stride * ws - g.pad;
     return r;
   }
   VP_HD float a_elem(const ARow& r, int k) const {
     if (!r.valid || k >= K) return 0.f;
     int tap = (int)g.dCb.div((uint32_t)k), c = k - tap * g.Cb;
-    int rr = tap / 5, qq = tap - rr * 5;
+    int rr = div_small(tap, g.ks), qq = tap - rr * g.ks;
     int h = r.h0 + rr, w = r.w0 + qq;
     if (h < 0 || h >= g.Hb || w < 0 || w >= g.Wb) return 0.f;
     return big[(size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c];
@@ -145,7 +146,7 @@ struct ProbF {
   VP_HD vp_f32x4 a_load(const ARow& r, int k, const ZCtx&) const {
     if (vec) {   // branch-free: always load (address clamped to element 0), then select
       int tap = (int)g.dCb.div((uint32_t)k), c = k - tap * g.Cb;
-      int rr = div_small(tap, 5), qq = tap - rr * 5;
+      int rr = div_small(tap, g.ks), qq = tap - rr * g.ks;
       int h = r.h0 + rr, w = r.w0 + qq;
       const bool ok = r.valid && k < K && h >= 0 && h < g.Hb && w >= 0 && w < g.Wb;
       return ld4(ok ? big + (size_t)(r.pix_base + h * g.Wb + w) * g.Cb + c : reinterpret_cast<const float*>(zero));
@@ -193,7 +194,8 @@ struct ProbT {
   int M, N;
   int vec;  // Cs % 4 == 0
 
-  struct ZCtx { int k_begin, k_end, ph, pw, th, tw; };
+  // phase (ph, pw) of the output: taps r = r0 + s*r' (r0 = (ph+pad) mod s), source row = q + bh - r'
+  struct ZCtx { int k_begin, k_end, ph, pw, th, tw, r0h, r0w, bh, bw; };
   struct ARow { int pix_base, q, p, valid; };
   struct BRow { int off, valid; };
 
@@ -201,8 +203,12 @@ struct ProbT {
     int s = g.stride;
     z.ph = zi / s;
     z.pw = zi - z.ph * s;
-    z.th = (5 - z.ph + s - 1) / s;
-    z.tw = (5 - z.pw + s - 1) / s;
+    z.r0h = (z.ph + g.pad) % s;
+    z.r0w = (z.pw + g.pad) % s;
+    z.th = z.r0h < g.ks ? (g.ks - z.r0h + s - 1) / s : 0;
+    z.tw = z.r0w < g.ks ? (g.ks - z.r0w + s - 1) / s : 0;
+    z.bh = (z.ph + g.pad - z.r0h) / s;
+    z.bw = (z.pw + g.pad - z.r0w) / s;
     z.k_begin = 0;
     z.k_end = z.th * z.tw * g.Cs;
   }
@@ -221,8 +227,7 @@ struct ProbT {
     if (!r.valid || k >= z.k_end) return 0.f;
     int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
     int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-    int d0 = g.stride == 2 ? 1 : 2;
-    int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+    int h = r.q + z.bh - rp, w_ = r.p + z.bw - qp;
     if (h < 0 || h >= g.Hs || w_ < 0 || w_ >= g.Ws) return 0.f;
     return small[(size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c];
   }
@@ -230,8 +235,7 @@ struct ProbT {
     if (vec) {
       int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
       int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-      int d0 = g.stride == 2 ? 1 : 2;
-      int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+      int h = r.q + z.bh - rp, w_ = r.p + z.bw - qp;
       const bool ok = r.valid && k < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
       return ld4(ok ? small + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : reinterpret_cast<const float*>(zero));
     }
@@ -241,21 +245,21 @@ struct ProbT {
   VP_HD BRow b_row(int n, const ZCtx&) const {
     BRow r;
     r.valid = n < N;
-    r.off = (r.valid ? n : 0) * kTaps * g.Cs;
+    r.off = (r.valid ? n : 0) * g.nt * g.Cs;
     return r;
   }
   VP_HD float b_elem(const BRow& r, int k, const ZCtx& z) const {
     if (!r.valid || k >= z.k_end) return 0.f;
     int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
     int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-    int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+    int tap = (z.r0h + g.stride * rp) * g.ks + (z.r0w + g.stride * qp);
     return w[(size_t)r.off + tap * g.Cs + c];
   }
   VP_HD vp_f32x4 b_load(const BRow& r, int k, const ZCtx& z) const {
     if (vec) {
       int t = (int)g.dCs.div((uint32_t)k), c = k - t * g.Cs;
       int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-      int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+      int tap = (z.r0h + g.stride * rp) * g.ks + (z.r0w + g.stride * qp);
       const bool ok = r.valid && k < z.k_end;
       return ld4(ok ? w + (size_t)r.off + tap * g.Cs + c : reinterpret_cast<const float*>(zero));
     }
@@ -268,6 +272,7 @@ struct ProbT {
     int rem = m - b * (g.Hs * g.Ws);
     int q = (int)g.dW.div((uint32_t)rem), p = rem - q * g.Ws;
     int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
+    if (oh >= g.Hb || ow >= g.Wb) return;   // odd big sizes: the last phase row/column does not exist
     out[((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n] = v;
   }
 };
@@ -292,8 +297,8 @@ struct ProbW {
   VP_HD void z_setup(int zi, ZCtx& z) const {
     z.tap = zi / nsplit;
     z.split = zi - z.tap * nsplit;
-    z.rr = z.tap / 5;
-    z.qq = z.tap - z.rr * 5;
+    z.rr = div_small(z.tap, g.ks);
+    z.qq = z.tap - z.rr * g.ks;
     z.k_begin = z.split * k_per_split;
     int e = z.k_begin + k_per_split;
     z.k_end = e < K ? e : K;
@@ -314,7 +319,7 @@ struct ProbW {
     int b = (int)g.dHW.div((uint32_t)k);
     int rem = k - b * (g.Hs * g.Ws);
     int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
-    int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
+    int h = g.stride * hs - g.pad + z.rr, w_ = g.stride * ws - g.pad + z.qq;
     if (h < 0 || h >= g.Hb || w_ < 0 || w_ >= g.Wb) return zero4();
     const float* p = big + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb;
     if (vec_b && n + 3 < N) return ld4(p + n);
@@ -325,7 +330,7 @@ struct ProbW {
   }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
-    slab[(((size_t)z.split * kTaps + z.tap) * M + m) * N + n] = v;
+    slab[(((size_t)z.split * g.nt + z.tap) * M + m) * N + n] = v;
   }
 };
 
@@ -415,10 +420,13 @@ struct ProbG {
 // ---------------------------------------------------------------------------------------------
 namespace vp {
 
-inline ConvGeom make_geom(int B, int Hs, int Ws, int Cs, int Cb, int stride) {
+// big side defaults to stride*small (the VAE's layers); Conv2d with odd inputs passes Hb/Wb explicitly
+// (Hs = floor((Hb + 2*pad - ks)/stride) + 1).
+inline ConvGeom make_geom(int B, int Hs, int Ws, int Cs, int Cb, int stride, int ks = 5, int Hb = 0, int Wb = 0) {
   ConvGeom g;
-  g.B = B; g.Hs = Hs; g.Ws = Ws; g.Hb = Hs * stride; g.Wb = Ws * stride;
+  g.B = B; g.Hs = Hs; g.Ws = Ws; g.Hb = Hb > 0 ? Hb : Hs * stride; g.Wb = Wb > 0 ? Wb : Ws * stride;
   g.Cs = Cs; g.Cb = Cb; g.stride = stride;
+  g.ks = ks; g.pad = (ks - 1) / 2; g.nt = ks * ks;
   g.dHW = make_fastdiv((uint32_t)(Hs * Ws)); g.dW = make_fastdiv((uint32_t)Ws);
   g.dCs = make_fastdiv((uint32_t)Cs); g.dCb = make_fastdiv((uint32_t)Cb);
   return g;
@@ -430,7 +438,7 @@ inline ProbF make_probF(const float* big, const float* wp0, const float* bias, f
   ProbF p;
   p.zero = vp_zero_page();
   p.big = big; p.w = wp0; p.bias = bias; p.out = out; p.g = g; p.act = act;
-  p.M = g.B * g.Hs * g.Ws; p.N = g.Cs; p.K = kTaps * g.Cb;
+  p.M = g.B * g.Hs * g.Ws; p.N = g.Cs; p.K = g.nt * g.Cb;
   p.vec = (g.Cb % 4 == 0);
   return p;
 }
@@ -447,7 +455,7 @@ inline ProbT make_probT(const float* small, const float* wp1, float* out, const 
 // K (= pixels) is split so that tiles * 25 taps * nsplit fills the 256 CUs a few times over.
 inline int wgrad_nsplit(const ConvGeom& g) {
   long K = (long)g.B * g.Hs * g.Ws;
-  long tiles = ((g.Cs + 127) / 128) * (long)((g.Cb + 127) / 128) * kTaps;
+  long tiles = ((g.Cs + 127) / 128) * (long)((g.Cb + 127) / 128) * g.nt;
   long want = (512 + tiles - 1) / tiles;
   long maxs = (K + 511) / 512;  // keep >= 16 K-tiles of 32 per split
   long s = want < maxs ? want : maxs;
@@ -469,7 +477,7 @@ inline ProbW make_probW(const float* big, const float* small, float* slab, const
 }
 
 inline size_t wgrad_slab_floats(const ConvGeom& g, int nsplit) {
-  return (size_t)nsplit * kTaps * g.Cs * g.Cb;
+  return (size_t)nsplit * g.nt * g.Cs * g.Cb;
 }
 
 inline int gemm_nsplit(long M, long N, long K) {

@@ -162,6 +162,108 @@ class _UnflattenNCHW(Function):
         return ops.nhwc_to_nchw(dy).reshape(dy.shape[0], -1), None, None, None
 
 
+class _ConvK(Function):
+    """nn.Conv2d(kernel k in {1,3,5}, stride 1|2, padding (k-1)//2) -- models/blocks.py:9-17."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride: int):
+        x = _cl(x)
+        ks = weight.shape[2]
+        p0, _ = ops.pack_w(weight, True, False)
+        y = ops.conv_gather(x, p0, bias, ks, stride, ACT_NONE)
+        ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _cl(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            _, p1 = ops.pack_w(weight, False, True)
+            dx = ops.conv_scatter(dy, p1, ctx.ks, ctx.stride, x.shape[2], x.shape[3])
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(x, dy, ctx.ks, ctx.stride)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            B, C, H, W = dy.shape
+            db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C))
+        return dx, dw, db, None
+
+
+class _Act(Function):
+    """Standalone activation (conv + bias + act blocks with bn=None, models/blocks.py:24-30)."""
+
+    @staticmethod
+    def forward(ctx, x, act: int, slope: float):
+        y = ops.act_fwd(x if (x.dim() != 4 or ops._is_nhwc(x)) else _cl(x), act, slope)
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _cl(dy) if dy.dim() == 4 else dy.contiguous()
+        return ops.act_bwd_from_y(y, dy, ctx.act, ctx.slope), None, None
+
+
+class _InstanceNormAct(Function):
+    """nn.InstanceNorm2d (affine=False, no running stats, eps 1e-5) + activation: per-(image, channel) statistics.
+    Runs the BatchNorm kernels on each image's [H*W][C] NHWC slice."""
+
+    @staticmethod
+    def forward(ctx, x, eps: float, act: int, slope: float):
+        x = _cl(x)
+        B = x.shape[0]
+        y = torch.empty_like(x)
+        means, rstds = [], []
+        for b in range(B):
+            xb = x[b:b + 1]
+            mean, rstd = ops.bn_stats(xb, eps, 0.0)
+            yb = ops.bn_act_fwd(xb, mean, rstd, None, None, act, slope)
+            y[b:b + 1].copy_(yb)
+            means.append(mean); rstds.append(rstd)
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(x, torch.stack(means), torch.stack(rstds))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, means, rstds = ctx.saved_tensors
+        dy = _cl(dy)
+        dx = torch.empty_like(x)
+        for b in range(x.shape[0]):
+            dxb, _, _ = ops.bn_act_bwd(x[b:b + 1], dy[b:b + 1], means[b], rstds[b], None, None, ctx.act, ctx.slope, True, False)
+            dx[b:b + 1].copy_(dxb)
+        return dx, None, None, None
+
+
+class _Upsample2x(Function):
+    """F.interpolate(scale_factor=2, mode='bilinear') -- models/blocks.py:145."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2x_fwd(_cl(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2x_bwd(_cl(dy))
+
+
+class _AddCoords(Function):
+    """AddCoords (models/blocks.py:97-112)."""
+
+    @staticmethod
+    def forward(ctx, x, normalize: bool):
+        ctx.C = x.shape[1]
+        return ops.add_coords(_cl(x), normalize)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.slice_channels(_cl(dy), ctx.C), None
+
+
 class _Reparam(Function):
     @staticmethod
     def forward(ctx, mu, logvar, eps):
@@ -226,6 +328,28 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training: bool, mo
 
 def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias)
+
+
+def conv2d(x, weight, bias=None, stride: int = 1):
+    """k x k convolution, k in {1,3,5}, padding (k-1)//2 (models/blocks.py Conv2d)."""
+    return _ConvK.apply(x, weight, bias, stride)
+
+
+def activation(x, act: Optional[str], slope: float = 0.0):
+    code = ACT_CODES[act]
+    return x if code == ACT_NONE else _Act.apply(x, code, slope)
+
+
+def instance_norm_act(x, eps: float = 1e-5, act: Optional[str] = None, slope: float = 0.0):
+    return _InstanceNormAct.apply(x, eps, ACT_CODES[act], slope)
+
+
+def upsample2x_bilinear(x):
+    return _Upsample2x.apply(x)
+
+
+def add_coords(x, normalize: bool = False):
+    return _AddCoords.apply(x, normalize)
 
 
 def flatten_nchw(x):

@@ -347,3 +347,81 @@ def conv5_wgrad_bf16x3(big_split, shape_big, small_split, shape_small, stride: i
     dw = torch.empty((Cs, Cb, 5, 5), dtype=torch.float32, device=big_split.device)
     _lib.call("vp_conv5_wgrad_bf16x3", _pv(big_split), _pv(small_split), _p(dw), B, Hs, Ws, Cb, Cs, stride, _p(ws), ws.numel() * 4, _stream())
     return dw
+
+
+# ---- k x k convolution families (models/blocks.py vocabulary) ------------------------------------------------
+def pack_w(w_ref: torch.Tensor, want_p0: bool, want_p1: bool):
+    """w_ref [Cs][Cb][k][k] -> p0 [Cs][k*k][Cb], p1 [Cb][k*k][Cs]."""
+    Cs, Cb, ks = w_ref.shape[0], w_ref.shape[1], w_ref.shape[2]
+    assert w_ref.shape[3] == ks
+    w_ref = w_ref.contiguous()
+    p0 = torch.empty((Cs, ks * ks, Cb), dtype=torch.float32, device=w_ref.device) if want_p0 else None
+    p1 = torch.empty((Cb, ks * ks, Cs), dtype=torch.float32, device=w_ref.device) if want_p1 else None
+    _lib.call("vp_pack_w_f32", _p(w_ref), _p(p0), _p(p1), Cs, Cb, ks, _stream())
+    return p0, p1
+
+
+def conv_out_size(n: int, ks: int, stride: int) -> int:
+    return (n + 2 * ((ks - 1) // 2) - ks) // stride + 1
+
+
+def conv_gather(big, w_p0, bias, ks: int, stride: int, act: int = ACT_NONE):
+    assert _is_nhwc(big)
+    B, Cb, Hb, Wb = big.shape
+    Cs = w_p0.shape[0]
+    Hs, Ws = conv_out_size(Hb, ks, stride), conv_out_size(Wb, ks, stride)
+    out = empty_cl(B, Cs, Hs, Ws, big)
+    _lib.call("vp_conv_gather_f32", _p(big), _p(w_p0), _p(bias), _p(out), B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride, act, _stream())
+    return out
+
+
+def conv_scatter(small, w_p1, ks: int, stride: int, Hb: int, Wb: int):
+    assert _is_nhwc(small)
+    B, Cs, Hs, Ws = small.shape
+    Cb = w_p1.shape[0]
+    out = empty_cl(B, Cb, Hb, Wb, small)
+    _lib.call("vp_conv_scatter_f32", _p(small), _p(w_p1), _p(out), B, Hs, Ws, Hb, Wb, Cs, Cb, ks, stride, _stream())
+    return out
+
+
+def conv_wgrad(big, small, ks: int, stride: int):
+    assert _is_nhwc(big) and _is_nhwc(small)
+    B, Cb, Hb, Wb = big.shape
+    _, Cs, Hs, Ws = small.shape
+    nbytes = _lib.load().vp_conv_wgrad_workspace_bytes(B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride)
+    ws = _ws(nbytes, big)
+    dw = torch.empty((Cs, Cb, ks, ks), dtype=torch.float32, device=big.device)
+    _lib.call("vp_conv_wgrad_f32", _p(big), _p(small), _p(dw), B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride, _p(ws), ws.numel() * 4, _stream())
+    return dw
+
+
+def upsample2x_fwd(x):
+    assert _is_nhwc(x)
+    B, C, H, W = x.shape
+    y = empty_cl(B, C, 2 * H, 2 * W, x)
+    _lib.call("vp_upsample2x_bilinear_fwd_f32", _p(x), _p(y), B, H, W, C, _stream())
+    return y
+
+
+def upsample2x_bwd(dy):
+    assert _is_nhwc(dy)
+    B, C, Ho, Wo = dy.shape
+    dx = empty_cl(B, C, Ho // 2, Wo // 2, dy)
+    _lib.call("vp_upsample2x_bilinear_bwd_f32", _p(dy), _p(dx), B, Ho // 2, Wo // 2, C, _stream())
+    return dx
+
+
+def add_coords(x, normalize: bool):
+    assert _is_nhwc(x)
+    B, C, H, W = x.shape
+    out = empty_cl(B, C + 2, H, W, x)
+    _lib.call("vp_add_coords_f32", _p(x), _p(out), B, H, W, C, int(normalize), _stream())
+    return out
+
+
+def slice_channels(x, Cout: int):
+    assert _is_nhwc(x)
+    B, C, H, W = x.shape
+    out = empty_cl(B, Cout, H, W, x)
+    _lib.call("vp_slice_channels_f32", _p(x), _p(out), B * H * W, C, Cout, _stream())
+    return out
