@@ -35,6 +35,18 @@ CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32
               "vp_conv5_gather_bf16x3", "vp_conv5_scatter_bf16x3", "vp_conv5_wgrad_bf16x3"}
 
 
+def measured_traffic(api_name):
+    """HBM bytes per launch of a conv family from the committed PMC passes (profiles/*_traffic.json, newest round);
+    None when no measurement is on file for that kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get(api_name), os.path.basename(files[-1])
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +177,7 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if is16 else PEAK_FP32_MFMA_TFLOPS
         kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if is16
                  else "igemm_kernel, v_mfma_f32_32x32x2_f32")
+        traffic, traffic_src = measured_traffic(dom)
         ips = world * B * args.steps / elapsed
         out = {
             "metric": "images/sec (train step, 128x128 VAE)", "value": round(ips, 1), "unit": "images/sec",
@@ -180,7 +193,8 @@ def main():
             "loss": round(final_loss, 4),
             "roofline": {"bound": "mfma", "kernel": f"{dom} ({kdesc})",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None,
+                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
+                         "traffic_source": traffic_src,
                          "mfma_issue_frac": round(ach * (3 if is16 else 1) / peak, 4),
                          "launches": fam[dom][2], "avg_launch_ms": round(fam[dom][1] / fam[dom][2] * 1e3, 4),
                          "all_conv_families_tflops": round(tot_f / tot_t / 1e12, 2),
