@@ -13,6 +13,7 @@ X3_RTOL = 5e-5
 CASES = [  # (B, Hs, Cb, Cs, stride): channel counts multiples of 8
     (2, 4, 8, 8, 2), (2, 8, 64, 128, 2), (3, 5, 16, 24, 2), (8, 32, 32, 512, 2), (6, 64, 16, 64, 2),
     (2, 16, 128, 64, 2), (1, 8, 256, 256, 2), (2, 12, 64, 64, 1), (4, 16, 512, 256, 2),
+    (32, 8, 256, 256, 2), (2, 8, 192, 320, 2),
 ]
 
 
@@ -37,8 +38,14 @@ def test_bf16x3_families(B, Hs, Cb, Cs, stride):
     assert_close(ops.unsplit(p1).view(Cb, 25, Cs), w.permute(1, 2, 3, 0).reshape(Cb, 25, Cs), 2 ** -15, "p1")
     y = ops.conv5_gather_bf16x3(big_s, big.shape, p0, Cs, bias.to(DEV), stride, 0)
     assert_close(y, F.conv2d(big, w, bias, stride=stride, padding=2), X3_RTOL, "gather bf16x3")
+    # without bias the few-tile / long-K shapes take the 2-way split-K path (atomic accumulation of two halves)
+    y0 = ops.conv5_gather_bf16x3(big_s, big.shape, p0, Cs, None, stride, 0)
+    assert_close(y0, F.conv2d(big, w, None, stride=stride, padding=2), X3_RTOL, "gather bf16x3 (no bias)")
+    y1 = ops.conv5_gather_bf16x3(big_s, big.shape, p0, Cs, None, stride, 0)
+    assert torch.equal(y0, y1), "split-K gather must be bit-reproducible"
     yt = ops.conv5_scatter_bf16x3(small_s, small.shape, p1, Cb, stride)
     assert_close(yt, F.conv_transpose2d(small, w, None, stride=stride, padding=2, output_padding=stride - 1), X3_RTOL, "scatter bf16x3")
+    assert torch.equal(yt, ops.conv5_scatter_bf16x3(small_s, small.shape, p1, Cb, stride)), "scatter must be bit-reproducible"
     wr = w.clone().requires_grad_(True)
     F.conv2d(big, wr, None, stride=stride, padding=2).backward(small)
     dw = ops.conv5_wgrad_bf16x3(big_s, big.shape, small_s, small.shape, stride)

@@ -111,7 +111,14 @@ int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const 
   p.w = (const u16*)w_p0_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
   p.bias = bias; p.out = small_out; p.act = act;
   p.M = B * Hs * Ws; p.N = Csmall; p.K = kTaps * Cbig;
-  launch_igemm16(p, p.M, p.N, 1, (hipStream_t)stream, Cbig);
+  // few output tiles and a long K (the 8x8-resolution layers: 256 workgroups = one per CU): split K in two and
+  // accumulate both halves with fp32 atomics onto a zeroed output (two addends: the sum does not depend on order)
+  const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64);
+  p.nsplit = (!bias && act == VP_ACT_NONE && Cbig % 64 == 0 && tiles < 384 && p.K >= 4096) ? 2 : 1;
+  p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
+  if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
+  launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig);
   return check_launch("vp_conv5_gather_bf16x3");
 }
 
@@ -126,7 +133,12 @@ int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, flo
   p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
   p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
   p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
-  launch_igemm16(p, p.M, p.N, stride * stride, (hipStream_t)stream, Csmall);
+  const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64) * stride * stride;
+  p.nsplit = (Csmall % 64 == 0 && tiles < 384 && 4 * Csmall >= 1024) ? 2 : 1;
+  if (p.nsplit == 2 &&
+      hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
+  launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
   return check_launch("vp_conv5_scatter_bf16x3");
 }
 

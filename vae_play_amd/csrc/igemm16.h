@@ -67,10 +67,15 @@ struct ProbF16 {
   const u16* w; size_t w_plane;         // packed P0 planes [Cs][25][Cb]
   const float* bias; float* out; const void* zero;
   ConvGeom g; int act; int M, N, K;
+  int nsplit, k_per_split;   // nsplit == 2: both halves of K are atomically added onto a zeroed output
   struct ZCtx { int k_begin, k_end; };
   struct ARow { int pix_base, h0, w0, valid; };
   struct BRow { int off, valid; };
-  VP_HD void z_setup(int, ZCtx& z) const { z.k_begin = 0; z.k_end = K; }
+  VP_HD void z_setup(int zi, ZCtx& z) const {
+    z.k_begin = zi * k_per_split;
+    const int e = z.k_begin + k_per_split;
+    z.k_end = e < K ? e : K;
+  }
   VP_HD ARow a_row(int m, const ZCtx&) const {
     ARow r; r.valid = m < M; int mm = r.valid ? m : 0;
     int b = (int)g.dHW.div((uint32_t)mm); int rem = mm - b * (g.Hs * g.Ws);
@@ -83,19 +88,19 @@ struct ProbF16 {
   // inside ONE tap, so tap -> (rr, qq) is computed from the workgroup-uniform k0 on the scalar unit; only
   // the bounds test and the address remain per-lane work (VALU per MFMA fell from 5-13 to ~3, PMC).
   template <bool FAST>
-  VP_HD u32x4_t a_load(const ARow& r, int k0, int k8, int plane, const ZCtx&) const {
+  VP_HD u32x4_t a_load(const ARow& r, int k0, int k8, int plane, const ZCtx& z) const {
     const int kt = FAST ? k0 : k0 + k8;
     const int tap = (int)g.dCb.div((uint32_t)kt);
     const int c = k0 + k8 - tap * g.Cb;
     const int rr = div_small(tap, 5), qq = tap - rr * 5;
     const int h = r.h0 + rr, w_ = r.w0 + qq;
-    const bool ok = r.valid && kt < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+    const bool ok = r.valid && kt < z.k_end && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
     return ld16(ok ? big + plane * big_plane + (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c : reinterpret_cast<const u16*>(zero));
   }
   VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * K; return r; }
   template <bool FAST>
-  VP_HD u32x4_t b_load(const BRow& r, int k0, int k8, int plane, const ZCtx&) const {
-    const bool ok = r.valid && (FAST ? k0 : k0 + k8) < K;
+  VP_HD u32x4_t b_load(const BRow& r, int k0, int k8, int plane, const ZCtx& z) const {
+    const bool ok = r.valid && (FAST ? k0 : k0 + k8) < z.k_end;
     return ld16(ok ? w + plane * w_plane + (size_t)r.off + k0 + k8 : reinterpret_cast<const u16*>(zero));
   }
   // FAST row-level form: one bounds test + one address per (row, K-tile); the caller adds plane / chunk offsets
@@ -111,20 +116,20 @@ struct ProbF16 {
     c0 = cc << SH;
   }
   template <int SH = 6>
-  VP_HD bool a_base(const ARow& r, int k0, const ZCtx&, size_t& off) const {
+  VP_HD bool a_base(const ARow& r, int k0, const ZCtx& z, size_t& off) const {
     int tap, c0;
     fast_tile<SH>(k0, kTaps, tap, c0);
     const int rr = div_small(tap, 5), qq = tap - rr * 5;
     const int h = r.h0 + rr, w_ = r.w0 + qq;
     off = (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c0;
-    return r.valid && k0 < K && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+    return r.valid && k0 < z.k_end && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
   }
   template <int SH = 6>
-  VP_HD bool b_base(const BRow& r, int k0, const ZCtx&, size_t& off) const {
+  VP_HD bool b_base(const BRow& r, int k0, const ZCtx& z, size_t& off) const {
     int tap, c0;
     fast_tile<SH>(k0, kTaps, tap, c0);
     off = (size_t)r.off + tap * g.Cb + c0;
-    return r.valid && k0 < K;
+    return r.valid && k0 < z.k_end;
   }
   VP_HD const u16* a_ptr() const { return big; }
   VP_HD size_t a_plane() const { return big_plane; }
@@ -132,6 +137,9 @@ struct ProbF16 {
   VP_HD size_t b_plane() const { return w_plane; }
   VP_HD void store(int m, int n, float v, const ZCtx&) const {
     if (m >= M || n >= N) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nsplit > 1) { atomicAdd(out + (size_t)m * N + n, v); return; }   // 2 addends onto 0: order-independent
+#endif
     if (bias) v += bias[n];
     if (act == ACT_SIGMOID) v = 1.f / (1.f + __builtin_expf(-v));
     out[(size_t)m * N + n] = v;
@@ -144,13 +152,19 @@ struct ProbT16 {
   const u16* small; size_t small_plane;
   const u16* w; size_t w_plane;          // packed P1 planes [Cb][25][Cs]
   float* out; const void* zero; ConvGeom g; int M, N;
+  int nsplit;                // 1, or 2: z = phase*2 + half, halves atomically added onto a zeroed output
   struct ZCtx { int k_begin, k_end, ph, pw, th, tw; };
   struct ARow { int pix_base, q, p, valid; };
   struct BRow { int off, valid; };
   VP_HD void z_setup(int zi, ZCtx& z) const {
-    int s = g.stride; z.ph = zi / s; z.pw = zi - z.ph * s;
+    const int phase = zi / nsplit, half = zi - phase * nsplit;
+    int s = g.stride; z.ph = phase / s; z.pw = phase - z.ph * s;
     z.th = (5 - z.ph + s - 1) / s; z.tw = (5 - z.pw + s - 1) / s;
-    z.k_begin = 0; z.k_end = z.th * z.tw * g.Cs;
+    const int kall = z.th * z.tw * g.Cs;
+    // split at a multiple of 64 so that FAST tiles stay inside one tap / chunk
+    const int kh = nsplit > 1 ? (((kall / 64) + 1) / 2) * 64 : kall;
+    z.k_begin = half * kh;
+    z.k_end = half + 1 < nsplit ? kh : kall;
   }
   VP_HD ARow a_row(int m, const ZCtx&) const {
     ARow r; r.valid = m < M; int mm = r.valid ? m : 0;
@@ -215,7 +229,11 @@ struct ProbT16 {
     int b = (int)g.dHW.div((uint32_t)m); int rem = m - b * (g.Hs * g.Ws);
     int q = (int)g.dW.div((uint32_t)rem), p = rem - q * g.Ws;
     int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
-    out[((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n] = v;
+    float* dst = out + ((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nsplit > 1) { atomicAdd(dst, v); return; }
+#endif
+    *dst = v;
   }
 };
 
