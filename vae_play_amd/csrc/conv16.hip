@@ -1,6 +1,7 @@
 // Split-bf16 ("bf16x3") convolution families: C ABI + the producers of split planes.
 #include "common.h"
 #include "igemm16.h"
+#include "halo.h"
 #include "narrow.h"
 #include "split.h"
 
@@ -77,6 +78,12 @@ int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hip
 
 using namespace vp;
 
+// VP_HALO=0 sends the narrow-channel layers back to the implicit-GEMM kernels (A/B runs)
+static bool halo_enabled() {
+  static const bool on = [] { const char* e = getenv("VP_HALO"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 extern "C" {
 
 int vp_split_f32(const float* x, void* out_split, size_t n, vp_stream stream) {
@@ -104,6 +111,9 @@ int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const 
   VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Cbig % 8 == 0, "vp_conv5_gather_bf16x3: Cbig must be a multiple of 8");
   VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_gather_bf16x3: stride must be 1 or 2");
   VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv5_gather_bf16x3: epilogue supports none|sigmoid");
+  if (halo_enabled())
+    if (const int kind = halo_gather_kind(B, Hs, Ws, Cbig, Csmall, stride))
+      return halo_gather_launch(kind, big_split, w_p0_split, bias, small_out, B, Hs, Ws, Cbig, Csmall, stride, act, (hipStream_t)stream);
   ProbF16 p;
   p.zero = vp_zero_page();
   p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
@@ -127,6 +137,9 @@ int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, flo
   VP_REQUIRE(small_split && w_p1_split && big_out, "vp_conv5_scatter_bf16x3: null pointer");
   VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Csmall % 8 == 0, "vp_conv5_scatter_bf16x3: Csmall must be a multiple of 8");
   VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_scatter_bf16x3: stride must be 1 or 2");
+  if (halo_enabled())
+    if (const int kind = halo_scatter_kind(B, Hs, Ws, Csmall, Cbig, stride))
+      return halo_scatter_launch(kind, small_split, w_p1_split, big_out, B, Hs, Ws, Csmall, Cbig, (hipStream_t)stream);
   ProbT16 p;
   p.zero = vp_zero_page();
   p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);

@@ -1,5 +1,6 @@
 // HBM-bound glue kernels: layout transposes, latent (reparameterise + KL), per-pixel BCE with
 // wavefront reductions, and the fused flat-arena optimiser steps.
+#include <stdlib.h>
 #include "common.h"
 #include "problems.h"
 #include "split.h"
@@ -264,11 +265,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
                                                    float one_minus_b2, float eps, float step_size, float bc2_sqrt,
                                                    float grad_scale) {
   const size_t n4 = n / 4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    vp_f32x4 pv = *reinterpret_cast<vp_f32x4*>(p + i * 4);
-    vp_f32x4 gv = *reinterpret_cast<const vp_f32x4*>(g + i * 4);
-    vp_f32x4 mv = *reinterpret_cast<vp_f32x4*>(m + i * 4);
-    vp_f32x4 vv = *reinterpret_cast<vp_f32x4*>(v + i * 4);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  auto upd = [&](vp_f32x4& pv, const vp_f32x4& gv, vp_f32x4& mv, vp_f32x4& vv) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gr = gv[j] * grad_scale;
@@ -277,9 +275,36 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
       const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
       pv[j] = pv[j] - step_size * (mv[j] / denom);
     }
-    *reinterpret_cast<vp_f32x4*>(p + i * 4) = pv;
-    *reinterpret_cast<vp_f32x4*>(m + i * 4) = mv;
-    *reinterpret_cast<vp_f32x4*>(v + i * 4) = vv;
+  };
+  // two independent 16-B quads per thread and iteration: 8 loads in flight before the first use; the moments
+  // are streamed with non-temporal accesses (touched once per step), p and g stay cacheable for their consumers
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const size_t a = i * 4, b = (i + stride) * 4;
+    vp_f32x4 pa = *reinterpret_cast<vp_f32x4*>(p + a), pb = *reinterpret_cast<vp_f32x4*>(p + b);
+    vp_f32x4 ga = *reinterpret_cast<const vp_f32x4*>(g + a), gb = *reinterpret_cast<const vp_f32x4*>(g + b);
+    vp_f32x4 ma = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(m + a));
+    vp_f32x4 mb = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(m + b));
+    vp_f32x4 va = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(v + a));
+    vp_f32x4 vb = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(v + b));
+    upd(pa, ga, ma, va);
+    upd(pb, gb, mb, vb);
+    *reinterpret_cast<vp_f32x4*>(p + a) = pa;
+    *reinterpret_cast<vp_f32x4*>(p + b) = pb;
+    __builtin_nontemporal_store(ma, reinterpret_cast<vp_f32x4*>(m + a));
+    __builtin_nontemporal_store(mb, reinterpret_cast<vp_f32x4*>(m + b));
+    __builtin_nontemporal_store(va, reinterpret_cast<vp_f32x4*>(v + a));
+    __builtin_nontemporal_store(vb, reinterpret_cast<vp_f32x4*>(v + b));
+  }
+  if (i < n4) {
+    const size_t a = i * 4;
+    vp_f32x4 pa = *reinterpret_cast<vp_f32x4*>(p + a);
+    vp_f32x4 ga = *reinterpret_cast<const vp_f32x4*>(g + a);
+    vp_f32x4 ma = *reinterpret_cast<vp_f32x4*>(m + a), va = *reinterpret_cast<vp_f32x4*>(v + a);
+    upd(pa, ga, ma, va);
+    *reinterpret_cast<vp_f32x4*>(p + a) = pa;
+    *reinterpret_cast<vp_f32x4*>(m + a) = ma;
+    *reinterpret_cast<vp_f32x4*>(v + a) = va;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const size_t i = n4 * 4 + threadIdx.x;
@@ -415,7 +440,8 @@ int vp_adam_f32(float* p, const float* g, float* m, float* v, size_t n, float lr
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+  static const int cap = [] { const char* e = getenv("VP_ADAM_BLOCKS"); return e ? atoi(e) : 256 * 64; }();
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, cap)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                      1.f - beta1, beta2, 1.f - beta2, eps, step_size, bc2_sqrt, grad_scale);
   return check_launch("vp_adam_f32");
 }

@@ -317,11 +317,11 @@ template <class P, int BM, int BN, int WM, int WN, int BKT, bool FAST>
 __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(BKT == 32 || BKT == 64, "K-tile depth");
-  static_assert(!FAST || P::A_KM || BKT == 64, "FAST gather/scatter kernels decompose k0 in 64-deep tiles");
+  constexpr int SH = BKT == 64 ? 6 : 5;       // FAST gather/scatter kernels decompose k0 in BKT-deep channel chunks
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
   constexpr int KC = BKT / 8;                 // 16-B chunks per row and plane
-  constexpr int NA = BM * KC / 128, NB = BN * KC / 128;   // 16-B chunks per thread per K-tile (both planes)
+  constexpr int NA_KM = BM * KC / 128, NB_KM = BN * KC / 128;   // 16-B chunks per thread per K-tile (both planes)
   constexpr int A_PLANE = Lds16<BM, P::A_KM, BKT>::plane_bytes;
   constexpr int B_PLANE = Lds16<BN, P::B_KM, BKT>::plane_bytes;
   constexpr int MKS = MkStride<BKT>::bytes;
@@ -331,9 +331,10 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   // ds_write_b128 group (2 rows x 4 lanes) covers 32 distinct banks.
   constexpr int TPR = 4, RPP = 256 / TPR;     // 64 rows per pass
   constexpr int CPT = 2 * KC / TPR, CPH = CPT / 2;   // chunks per thread per row / per plane
-  constexpr int NRA = BM / RPP, NRB = BN / RPP;
-  static_assert(P::A_KM || (NRA >= 1 && NRA * CPT == NA), "MK staging map (A)");
-  static_assert(P::B_KM || (NRB >= 1 && NRB * CPT == NB), "MK staging map (B)");
+  constexpr int NRA = (BM + RPP - 1) / RPP, NRB = (BN + RPP - 1) / RPP;   // a 32-row operand uses half the threads
+  constexpr bool A_PART = BM < RPP, B_PART = BN < RPP;
+  constexpr int NA = P::A_KM ? NA_KM : NRA * CPT, NB = P::B_KM ? NB_KM : NRB * CPT;
+  static_assert(NA >= 1 && NB >= 1, "staging map");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_PLANE + 2 * B_PLANE];
   unsigned char* As = lds;                   // [plane][...]
   unsigned char* Bs = lds + 2 * A_PLANE;
@@ -352,23 +353,25 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   Rows16A<P, (P::A_KM ? 1 : NRA), P::A_KM> ra;
   Rows16B<P, (P::B_KM ? 1 : NRB), P::B_KM> rb;
   const int l4 = tid % TPR, srow = tid / TPR;
+  const bool a_on = !A_PART || srow < BM, b_on = !B_PART || srow < BN;
   if constexpr (!P::A_KM) {
 #pragma unroll
-    for (int i = 0; i < NRA; ++i) ra.r[i] = p.a_row(m0 + srow + RPP * i, z);
+    for (int i = 0; i < NRA; ++i) ra.r[i] = p.a_row(m0 + (a_on ? srow : 0) + RPP * i, z);
   }
   if constexpr (!P::B_KM) {
 #pragma unroll
-    for (int i = 0; i < NRB; ++i) rb.r[i] = p.b_row(n0 + srow + RPP * i, z);
+    for (int i = 0; i < NRB; ++i) rb.r[i] = p.b_row(n0 + (b_on ? srow : 0) + RPP * i, z);
   }
   u32x4_t sa[NA], sb[NB];
 
   auto stage_load = [&](int k0) {
     if constexpr (!P::A_KM) {
+      if (a_on)
 #pragma unroll
       for (int i = 0; i < NRA; ++i) {
         if constexpr (FAST) {
           size_t off;
-          const bool ok = p.a_base(ra.r[i], k0, z, off);
+          const bool ok = p.template a_base<SH>(ra.r[i], k0, z, off);
           const u16* b0 = ok ? p.a_ptr() + off : reinterpret_cast<const u16*>(p.zero);
           const u16* b1 = ok ? p.a_ptr() + p.a_plane() + off : reinterpret_cast<const u16*>(p.zero);
 #pragma unroll
@@ -408,11 +411,12 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       }
     }
     if constexpr (!P::B_KM) {
+      if (b_on)
 #pragma unroll
       for (int i = 0; i < NRB; ++i) {
         if constexpr (FAST) {
           size_t off;
-          const bool ok = p.b_base(rb.r[i], k0, z, off);
+          const bool ok = p.template b_base<SH>(rb.r[i], k0, z, off);
           const u16* b0 = ok ? p.b_ptr() + off : reinterpret_cast<const u16*>(p.zero);
           const u16* b1 = ok ? p.b_ptr() + p.b_plane() + off : reinterpret_cast<const u16*>(p.zero);
 #pragma unroll
@@ -452,6 +456,7 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   };
   auto stage_write = [&]() {
     if constexpr (!P::A_KM) {
+      if (a_on)
 #pragma unroll
       for (int i = 0; i < NRA; ++i)
 #pragma unroll
@@ -470,6 +475,7 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       }
     }
     if constexpr (!P::B_KM) {
+      if (b_on)
 #pragma unroll
       for (int i = 0; i < NRB; ++i)
 #pragma unroll
@@ -552,10 +558,12 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       }
 }
 
-struct Tile16 { int bm, bn; };
+struct Tile16 { int bm, bn; };   // wave grid: 2 x 2, or 4 x 1 for the 32-column tiles
 
-inline Tile16 choose_tile16(long M, long N, int gz) {
+inline Tile16 choose_tile16(long M, long N, int gz, bool km = false) {
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
+  // a 32-column operand (the 32-channel end of the last decoder block): 64-column tiles would idle half the MFMAs
+  if (N <= 32 && M >= 128) return (M >= 256 && blocks(256, 32) >= 384) ? Tile16{256, 32} : Tile16{128, 32};
   if (M >= 128 && N >= 128 && blocks(128, 128) >= 384) return {128, 128};
   if (M >= 128 && N >= 64 && blocks(128, 64) >= 384) return {128, 64};
   return {64, 64};
@@ -740,13 +748,19 @@ inline int igemm16_bk(bool km) {
 
 template <class P, int BKT, bool FAST>
 inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t stream) {
-  Tile16 t = choose_tile16(M, N, gz);
+  Tile16 t = choose_tile16(M, N, gz, P::A_KM);
   dim3 block(256);
   auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
   if (t.bm == 128 && t.bn == 128) {
     hipLaunchKernelGGL((igemm16_kernel<P, 128, 128, 2, 2, BKT, FAST>), grid(128, 128), block, 0, stream, p);
   } else if (t.bm == 128 && t.bn == 64) {
     hipLaunchKernelGGL((igemm16_kernel<P, 128, 64, 2, 2, BKT, FAST>), grid(128, 64), block, 0, stream, p);
+  } else if (t.bn == 32) {
+    // 32-column tiles run 32-deep K-tiles (LDS budget: 2-3 workgroups per CU)
+    if constexpr (BKT == 32) {
+      if (t.bm == 256) hipLaunchKernelGGL((igemm16_kernel<P, 256, 32, 4, 1, 32, FAST>), grid(256, 32), block, 0, stream, p);
+      else hipLaunchKernelGGL((igemm16_kernel<P, 128, 32, 4, 1, 32, FAST>), grid(128, 32), block, 0, stream, p);
+    }
   } else {
     hipLaunchKernelGGL((igemm16_kernel<P, 64, 64, 2, 2, BKT, FAST>), grid(64, 64), block, 0, stream, p);
   }
@@ -759,18 +773,24 @@ inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t strea
   const int bk = igemm16_bk(P::A_KM);
   if constexpr (P::A_KM) {
     // pixel-major (wgrad) family: FAST when the chosen tile lies fully inside M x N (no channel tails)
-    Tile16 t = choose_tile16(M, N, gz);
+    Tile16 t = choose_tile16(M, N, gz, true);
     const bool fast = (M % t.bm == 0) && (N % t.bn == 0);
     if (bk == 32) {
+      if (fast) launch_igemm16_bk<P, 32, true>(p, M, N, gz, stream);
+      else launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
+    } else if (t.bn == 32) {
       if (fast) launch_igemm16_bk<P, 32, true>(p, M, N, gz, stream);
       else launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
     } else {
       launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
     }
   } else {
-    if (ctile > 0 && ctile % 32 == 0 && igemm16_use_dma()) launch_igemm16_dma<P>(p, M, N, gz, stream);
-    else if (bk == 32) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
-    else if (ctile > 0 && ctile % 64 == 0) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream);
+    const Tile16 t0 = choose_tile16(M, N, gz);
+    const bool narrow = t0.bn == 32;   // tiles that exist with 32-deep K-tiles only
+    if (ctile > 0 && ctile % 32 == 0 && igemm16_use_dma() && !narrow) launch_igemm16_dma<P>(p, M, N, gz, stream);
+    else if (ctile > 0 && ctile % 64 == 0 && bk == 64 && !narrow) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream);
+    else if (ctile > 0 && ctile % 32 == 0) launch_igemm16_bk<P, 32, true>(p, M, N, gz, stream);   // 32-channel chunks
+    else if (bk == 32 || narrow) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
     else launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
   }
 }

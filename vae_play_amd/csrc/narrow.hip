@@ -236,9 +236,38 @@ __global__ void __launch_bounds__(256) wgrad_narrow_big_kernel(const float* __re
   }
 }
 
-// dw_ref[cs][cb][tap] = sum_split slab[split][tap][cs][cb]; 64 outputs x 4 split-lanes per workgroup.
+// dw_ref[j][tap] = sum_split slab[split][tap][j] with j = cs*Cb + cb.  One workgroup owns 64 consecutive j:
+// 4 tap-groups x 64 lanes read 256-B rows of every (split, tap) plane (coalesced, splits summed in order ->
+// bit-reproducible), the [64][nt] result is transposed through LDS and leaves as ONE contiguous 64*nt-float run.
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cs, int Cb,
                                                           int nsplit, int nt) {
+  __shared__ float tile[64 * 25];
+  const size_t cc = (size_t)Cs * Cb, per = cc * nt;
+  const size_t j0 = (size_t)blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const bool ok = j0 + lane < cc;
+  for (int t = tg; t < nt; t += 4) {
+    const float* src = slab + (size_t)t * cc + j0 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    int sp = 0;
+    if (ok) {
+      for (; sp + 1 < nsplit; sp += 2) {
+        s0 += src[(size_t)sp * per];
+        s1 += src[(size_t)(sp + 1) * per];
+      }
+      if (sp < nsplit) s0 += src[(size_t)sp * per];
+    }
+    tile[lane * nt + t] = s0 + s1;
+  }
+  __syncthreads();
+  const size_t base = j0 * nt;
+  for (int i = threadIdx.x; i < 64 * nt; i += 256)
+    if (base + i < per) dw[base + i] = tile[i];
+}
+
+// Few outputs, many slabs (the narrow kernels above: one slab per workgroup): 64 outputs x 4 split-lanes per workgroup.
+__global__ void __launch_bounds__(256) slab_reduce_deep_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cs, int Cb,
+                                                               int nsplit, int nt) {
   __shared__ float red[4][64];
   const size_t per = (size_t)nt * Cs * Cb;
   const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -318,13 +347,16 @@ int narrow_wgrad_launch(const float* big, const float* small, float* dw_ref, con
   int rc = check_launch("wgrad_narrow");
   if (rc) return rc;
   const size_t per = (size_t)kTaps * g.Cs * g.Cb;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, (const float*)ws, dw_ref, g.Cs, g.Cb, nblk, kTaps);
+  hipLaunchKernelGGL(slab_reduce_deep_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, (const float*)ws, dw_ref, g.Cs, g.Cb, nblk, kTaps);
   return check_launch("slab_reduce");
 }
 
 int slab_reduce_launch(const float* slab, float* dw_ref, int Cs, int Cb, int nsplit, hipStream_t s, int nt) {
-  const size_t per = (size_t)nt * Cs * Cb;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);
+  const size_t cc = (size_t)Cs * Cb, per = cc * nt;
+  if (cc >= 4096 && nt <= 25)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((cc + 63) / 64)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);
+  else
+    hipLaunchKernelGGL(slab_reduce_deep_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);
   return check_launch("slab_reduce");
 }
 

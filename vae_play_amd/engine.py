@@ -231,8 +231,11 @@ class FusedVAEStep:
                 fwd.add("vp_conv5_scatter_f32", P(dec_in[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
                         flops=fl, tag=f"dec{i}.fwd")
             nxt16 = i + 1 < L and dec16[i + 1]
+            # the last block feeds the final conv (fp32: its 3-channel side runs on the VALU kernels of narrow.hip;
+            # measured: padding 3 -> 32 output columns for the MFMA halo kernel is LDS-read bound and 25 % slower)
+            fin_halo = False
             u = None if nxt16 else self._buf(f"dec{i}.u", n_out)
-            u_s = self._sbuf(f"dec{i}.us", n_out) if nxt16 else None
+            u_s = self._sbuf(f"dec{i}.us", n_out) if (nxt16 or fin_halo) else None
             mean, rstd, ws = bn_block(f"dec{i}", tbuf, B * 4 * Hs * Hs, Cout, blk.bn, u, u_s)
             dec_rec.append((blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws))
             dec_in.append(u)
@@ -243,8 +246,14 @@ class FusedVAEStep:
         fp1 = self._buf("fin.p1", Cf * 25 * C)
         fwd.add("vp_pack_w5_f32", P(fin.weight), P(fp0), P(fp1), C, Cf)
         xt_nhwc = self._buf("xt_nhwc", B * S * S * C)
-        fwd.add("vp_conv5_gather_f32", P(dec_in[-1]), P(fp0), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, 1, _ACT_SIGMOID,
-                flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
+        if dec_in_s[-1] is not None:
+            fp0s = self._sbuf("fin.p0s", C * 25 * Cf)
+            fwd.add("vp_pack_w5_split", P(fin.weight), P(fp0s), None, C, Cf)
+            fwd.add("vp_conv5_gather_bf16x3", P(dec_in_s[-1]), P(fp0s), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, 1, _ACT_SIGMOID,
+                    flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
+        else:
+            fwd.add("vp_conv5_gather_f32", P(dec_in[-1]), P(fp0), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, 1, _ACT_SIGMOID,
+                    flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
         self.recon = self._buf("recon", 1)
         self.kl_sum = self._buf("kl_sum", 1)
         n_pix = B * S * S * C
