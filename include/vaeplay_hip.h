@@ -174,6 +174,13 @@ int vp_bce_sum_f32(const float* p, const float* t, size_t n, float* out, void* w
 int vp_bce_bwd_f32(const float* p, const float* t, const float* gptr, float gscale, float* dp, size_t n, vp_stream stream);
 /* fused sigmoid+BCE backward on the logits: dlogit = gscale * (p - t) */
 int vp_bce_sigmoid_bwd_f32(const float* p, const float* t, float gscale, float* dlogit, size_t n, vp_stream stream);
+/* ---- 0.5*(a-b)^2 (VaeGan.loss, models/networks.py:267 "nle" per element, :273 "mse" summed per row) ---- */
+int vp_half_sqdiff_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream);
+/* out[r] = sum_j 0.5*(a[r][j]-b[r][j])^2 for R contiguous rows of n_per_row elements */
+int vp_half_sqdiff_rowsum_f32(const float* a, const float* b, float* out, int R, int n_per_row, vp_stream stream);
+/* da = g*(a-b), db = -da (either may be NULL); g has one value per row (g_per_row=1) or per element (0) */
+int vp_half_sqdiff_bwd_f32(const float* a, const float* b, const float* g, float* da, float* db, int R, int n_per_row,
+                           int g_per_row, vp_stream stream);
 /* out[0] = sum x */
 int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream);
 

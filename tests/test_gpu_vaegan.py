@@ -1,0 +1,279 @@
+"""GPU parity tests of the VAE-GAN row: vae_play_amd.Discriminator / DirectDecoder / VaeGan on
+the HIP kernels against the vectors the REAL reference produced (tests/golden/vaegan_*.npz) and the oracle.
+Tolerance: NORTH_STAR_RTOL (1e-3 relative, BASELINE.json) for quantities that pass through the networks."""
+import pytest
+import torch
+
+from tests.util import NORTH_STAR_RTOL, assert_close, load_golden, record, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def dev(x):
+    return x.to(DEV)
+
+
+def _grad_check(name, grad, g, prefix, tol=NORTH_STAR_RTOL, term_scale=0.0):
+    """Gradient vs the reference's: full tensor when the fixture holds it, else 16 samples + the l2 norm.
+    ``term_scale`` = RMS of the largest single loss term's gradient for this tensor: train.py accumulates
+    loss_decoder (-(1-1e-6) * loss_discriminator) and loss_discriminator into the same .grad, so the
+    discriminator's net gradient is 1e-6 of its terms and the reference itself holds their fp32 cancellation
+    round-off there; such tensors are bounded by 2e-5 of the term magnitude (the per-loss gradients are compared
+    one by one against the oracle in test_vaegan_per_loss_gradients_vs_oracle)."""
+    from oracle import ref_cpu as O
+    gr = grad.detach().cpu().contiguous()
+    if f"{prefix}grad/{name}" in g:
+        return assert_close(gr, t(g[f"{prefix}grad/{name}"]), tol * 5, f"grad {name}")
+    l2 = g[f"{prefix}grad_l2/{name}"][0]
+    idx = O.sample_indices(gr.numel())
+    d = (gr.flatten()[idx].double() - t(g[f"{prefix}grad_samples/{name}"])).abs().max().item()
+    scale = max(l2 / gr.numel() ** 0.5, 1e-12)
+    slack = 2e-5 * term_scale
+    if scale < 1e-6 and term_scale == 0.0:
+        # a mathematically zero gradient (e.g. the BN scale in front of Linear -> BatchNorm1d with beta = 0: the
+        # loss is invariant to it); the reference holds fp32 round-off there, so only the magnitude is compared
+        assert gr.double().pow(2).sum().sqrt().item() / gr.numel() ** 0.5 < 1e-5, f"{name}: expected ~0 gradient"
+        return 0.0
+    assert d <= tol * scale * 30 + slack, f"grad samples {name}: {d} vs scale {scale} (term scale {term_scale})"
+    rel = abs(gr.double().pow(2).sum().sqrt().item() - l2) / (l2 + 1e-30)
+    record(f"grad_l2_rel/{name}", rel)
+    assert rel <= tol + slack * gr.numel() ** 0.5 / (l2 + 1e-30), f"grad l2 {name}: {rel}"
+    return rel
+
+
+def test_discriminator_against_reference_golden():
+    """models/networks.py:151-198 with 3 input channels and the tap below the top (recon_level=1): both modes,
+    output, the three input gradients, every parameter gradient, BN running statistics."""
+    import vae_play_amd as V
+    from oracle import ref_vaegan as G
+    g = load_golden("vaegan_disc_c3_l2")
+    disc = V.Discriminator(channel_in=3, recon_level=1, iter_level=2)
+    disc.load_state_dict(G.seeded_disc_weights(disc.state_dict(), int(g["weight_seed"])))
+    disc = disc.to(DEV).train()
+    xs = [dev(t(g[f"x{i}"])).requires_grad_(True) for i in range(3)]
+    for mode in ("REC", "GAN"):
+        disc.zero_grad()
+        for x in xs:
+            x.grad = None
+        y = disc(xs[0], xs[1], xs[2], mode)
+        assert_close(y, t(g[f"{mode}/y"]), NORTH_STAR_RTOL, f"{mode} y")
+        y.backward(dev(t(g[f"{mode}/gy"])))
+        for i in range(3):
+            assert_close(xs[i].grad, t(g[f"{mode}/dx{i}"]), NORTH_STAR_RTOL * 5, f"{mode} dx{i}")
+        for n, p in disc.named_parameters():
+            key = "discriminator." + n
+            if f"{mode}/grad/{key}" in g or f"{mode}/grad_l2/{key}" in g:
+                _grad_check(key, p.grad, g, f"{mode}/")
+            else:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{mode}: unexpected gradient for {n}"
+    sd = disc.state_dict()
+    for k in g:
+        if k.startswith("bn/"):
+            assert_close(sd[k[3:]], t(g[k]), NORTH_STAR_RTOL, f"running stat {k[3:]}")
+
+
+def test_direct_decoder_matches_oracle():
+    import vae_play_amd as V
+    from oracle import ref_vaegan as G
+    torch.manual_seed(11)
+    net = V.DirectDecoder(16)
+    p = {"param_encoder." + k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    z = torch.randn(5, 16)
+    gy = torch.randn(5, 3)
+    zo = z.clone().requires_grad_(True)
+    yo = G.direct_decoder_forward(p, zo)
+    yo.backward(gy)
+    zd = dev(z).requires_grad_(True)
+    y = net(zd)
+    y.backward(dev(gy))
+    assert_close(y, yo.detach(), 2e-5, "DirectDecoder y")
+    assert_close(zd.grad, zo.grad, 2e-5, "DirectDecoder dz")
+    for n, q in net.named_parameters():
+        assert_close(q.grad, p["param_encoder." + n].grad, 5e-5, f"DirectDecoder grad {n}")
+
+
+@pytest.mark.parametrize("name", ["vaegan_32x32_z16_b4", "vaegan_64x64_z32_b4"])
+def test_vaegan_train_step_against_reference_golden(name):
+    """train.py:43-78 on the drop-in VaeGan: forward (eps / z_p injected), VaeGan.loss, the five losses, the
+    accumulate-then-step backward (module.zero_grad + 5 x backward(retain_graph)) and four flat-arena RMSprop
+    steps, against the reference's outputs, losses, gradients, BN statistics and updated parameters."""
+    import torch.nn.functional as F
+    import vae_play_amd as V
+    from vae_play_amd import optim
+    from oracle import ref_cpu as O
+    from oracle import ref_vaegan as G
+    g = load_golden(name)
+    S, z, B, steps = (int(g[k]) for k in ("meta_S", "meta_z", "meta_B", "meta_steps"))
+    net = V.VaeGan(S, z)
+    missing = net.load_state_dict(G.init_vaegan_params(S, z, seed=0), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    net = net.to(DEV).train()
+    opts = [optim.RMSprop(m.parameters(), lr=1e-4) for m in (net.encoder, net.decoder, net.discriminator, net.param_encoder)]
+    x, targets, eps, z_p = (dev(t(g[k])) for k in ("x", "targets", "eps", "z_p"))
+    tol = NORTH_STAR_RTOL
+    for step in range(1, steps + 1):
+        x_tilde, disc_class, disc_layer, mus, logvar, params = net(x, eps=eps, z_p=z_p)
+        dl = (disc_layer[:B], disc_layer[B:-B], disc_layer[-B:])
+        dc = (disc_class[:B], disc_class[B:-B], disc_class[-B:])
+        terms = V.VaeGan.loss(x, x_tilde, *dl, *dc, mus, logvar, targets, params)
+        nle, kl, mse, bo, bp, bs, l1 = terms
+        lam = G.LAMBDA_MSE
+        losses = {"loss_recon": F.mse_loss(x, x_tilde), "loss_encoder": torch.sum(kl) + torch.sum(mse)}
+        losses["loss_discriminator"] = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+        losses["loss_decoder"] = torch.sum(lam * mse) - (1.0 - lam) * losses["loss_discriminator"]
+        losses["loss_aux"] = l1
+        names = [n for n, _ in net.named_parameters()]
+        plist = [p for _, p in net.named_parameters()]
+        term_scale = {n: 0.0 for n in names}
+        if step == 1:
+            for k in ("loss_encoder", "loss_decoder", "loss_discriminator"):
+                gs = torch.autograd.grad(losses[k], plist, retain_graph=True, allow_unused=True)
+                for n, gk in zip(names, gs):
+                    if gk is not None:
+                        term_scale[n] = max(term_scale[n], gk.double().pow(2).mean().sqrt().item())
+        net.zero_grad()                                    # train.py:68 (sets .grad to None: the arenas re-gather)
+        order = ("loss_recon", "loss_encoder", "loss_decoder", "loss_discriminator", "loss_aux")
+        for i, k in enumerate(order):
+            losses[k].backward(retain_graph=i + 1 < len(order))
+        if step == 1:
+            outs = {"x_tilde": x_tilde, "disc_class": disc_class, "disc_layer": disc_layer, "mus": mus, "logvar": logvar,
+                    "params": params, "nle": nle, "kl": kl, "mse": mse, "bce_dis_original": bo, "bce_dis_predicted": bp,
+                    "bce_dis_sampled": bs, "l1_enc_param": l1}
+            for k, v in outs.items():
+                v = v.detach()
+                if f"out/{k}" in g:
+                    assert_close(v.reshape(-1), t(g[f"out/{k}"]).reshape(-1), tol, k)
+                else:
+                    assert_close(v.cpu().contiguous().flatten()[::7][:8192], t(g[f"out_stride7/{k}"]), tol, k + "[::7]")
+                    l2 = g[f"out_l2/{k}"][0]
+                    assert abs(v.double().pow(2).sum().sqrt().item() - l2) <= tol * l2, k
+            for k, v in losses.items():
+                ref = g[f"loss/{k}"][0]
+                assert abs(v.item() - ref) <= tol * abs(ref) + 1e-6, f"{k}: {v.item()} vs {ref}"
+            for n, p in net.named_parameters():
+                _grad_check(n, p.grad, g, "", term_scale=term_scale[n])
+            sd = net.state_dict()
+            for k in g:
+                if k.startswith("bn/"):
+                    assert_close(sd[k[3:]].flatten()[:4096], t(g[k]).flatten(), tol, f"running stat {k[3:]}")
+                if k.startswith("nbt/"):
+                    assert int(sd[k[4:]]) == int(g[k]), k
+        if step == 1:
+            # RMSprop normalises the gradient: its first step moves every weight by lr/sqrt(1-alpha) = 10*lr in the
+            # direction of sign(g).  Where the reference's gradient is round-off (mathematically zero, or the
+            # discriminator's cancelling terms) that sign is noise, so those tensors are only bounded, not matched.
+            noisy = {}
+            for n, p in net.named_parameters():
+                net_scale = g[f"grad_l2/{n}"][0] / p.numel() ** 0.5
+                noisy[n] = net_scale < 1e-6 or net_scale < 1e-4 * term_scale[n]
+            assert not any(v for n, v in noisy.items() if n.startswith(("encoder.", "decoder.", "param_encoder.")))
+        for o in opts:
+            o.step()
+        max_move = 10.5 * 1e-4 * step
+        for n, p in net.named_parameters():
+            pv = p.detach().cpu().contiguous()
+            l2 = g[f"param{step}_l2/{n}"][0]
+            upd = max_move * pv.numel() ** 0.5
+            idx = O.sample_indices(pv.numel())
+            dd = (pv.flatten()[idx].double() - t(g[f"param{step}_samples/{n}"])).abs()
+            assert dd.max().item() <= 2 * max_move, f"param sample moved more than 2 * 10 * lr * step: {n}"
+            if noisy[n]:
+                continue
+            assert abs(pv.double().pow(2).sum().sqrt().item() - l2) <= 1e-5 * l2 + 0.02 * upd, f"param l2 after step {step}: {n}"
+            assert (dd > 0.05 * max_move + 1e-7).sum().item() <= max(2, dd.numel() // 8), f"param samples after step {step}: {n}"
+        # from step 2 on the discriminator's weights carry the noise-directed update described above, so only the
+        # loss that does not pass through it is held to the parity tolerance; the others must stay in the vicinity
+        ref = g[f"loss_step{step}/loss_recon"][0]
+        assert abs(losses["loss_recon"].item() - ref) <= tol * abs(ref) + 1e-7, f"step {step} loss_recon"
+        for k in ("loss_encoder", "loss_discriminator"):
+            ref = g[f"loss_step{step}/{k}"][0]
+            assert abs(losses[k].item() - ref) <= (tol if step == 1 else 0.15) * abs(ref) + 1e-6, f"step {step} {k}"
+
+
+def test_vaegan_per_loss_gradients_vs_oracle():
+    """Each of the five losses of train.py:61-66 differentiated ON ITS OWN (autograd.grad), every parameter, against
+    the oracle run on this host's CPU -- the accumulated gradient hides the discriminator's terms (they cancel to
+    1e-6), this does not."""
+    import torch.nn.functional as F
+    import vae_play_amd as V
+    from oracle import ref_cpu as O
+    from oracle import ref_vaegan as G
+    S, z, B = 32, 16, 4
+    x, targets, eps, z_p = G.synthetic_batch(B, S, z)
+    p = G.init_vaegan_params(S, z, seed=0)
+    O.require_grad(p)
+    _, o_losses = G.train_losses(p, x, targets, eps, z_p, S)
+    names = O.trainable_names(p)
+    net = V.VaeGan(S, z)
+    net.load_state_dict(G.init_vaegan_params(S, z, seed=0), strict=True)
+    net = net.to(DEV).train()
+    xd, td, ed, zd = dev(x), dev(targets), dev(eps), dev(z_p)
+    x_tilde, disc_class, disc_layer, mus, logvar, params = net(xd, eps=ed, z_p=zd)
+    dl = (disc_layer[:B], disc_layer[B:-B], disc_layer[-B:])
+    dc = (disc_class[:B], disc_class[B:-B], disc_class[-B:])
+    nle, kl, mse, bo, bp, bs, l1 = V.VaeGan.loss(xd, x_tilde, *dl, *dc, mus, logvar, td, params)
+    lam = G.LAMBDA_MSE
+    losses = {"loss_recon": F.mse_loss(xd, x_tilde), "loss_encoder": torch.sum(kl) + torch.sum(mse)}
+    losses["loss_discriminator"] = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+    losses["loss_decoder"] = torch.sum(lam * mse) - (1.0 - lam) * losses["loss_discriminator"]
+    losses["loss_aux"] = l1
+    ours = dict(net.named_parameters())
+    assert list(ours.keys()) == names
+    for k in ("loss_recon", "loss_encoder", "loss_decoder", "loss_discriminator", "loss_aux"):
+        assert abs(losses[k].item() - o_losses[k].item()) <= NORTH_STAR_RTOL * abs(o_losses[k].item()) + 1e-6, k
+        go = torch.autograd.grad(o_losses[k], [p[n] for n in names], retain_graph=True, allow_unused=True)
+        gd = torch.autograd.grad(losses[k], [ours[n] for n in names], retain_graph=True, allow_unused=True)
+        for n, a, b in zip(names, gd, go):
+            if b is None or float(b.abs().max()) == 0.0:
+                assert a is None or float(a.abs().max()) <= 1e-12, f"{k}: {n} must not receive a gradient"
+                continue
+            rms = b.double().pow(2).mean().sqrt().item()
+            top = max(r.double().pow(2).mean().sqrt().item() for r in go if r is not None)
+            if rms < 1e-6 * top:
+                assert a.double().pow(2).mean().sqrt().item() < 1e-4 * top, f"{k}: {n} expected ~0"
+                continue
+            assert_close(a, b, NORTH_STAR_RTOL * 5, f"{k} d/d {n}")
+
+
+def test_backward_all_equals_five_accumulated_passes():
+    import torch.nn.functional as F
+    import vae_play_amd as V
+    from oracle import ref_vaegan as G
+    S, z, B = 32, 16, 4
+    x, targets, eps, z_p = (dev(a) for a in G.synthetic_batch(B, S, z))
+    grads = []
+    for fused in (False, True):
+        net = V.VaeGan(S, z)
+        net.load_state_dict(G.init_vaegan_params(S, z, seed=0), strict=True)
+        net = net.to(DEV).train()
+        x_tilde, disc_class, disc_layer, mus, logvar, params = net(x, eps=eps, z_p=z_p)
+        dl = (disc_layer[:B], disc_layer[B:-B], disc_layer[-B:])
+        dc = (disc_class[:B], disc_class[B:-B], disc_class[-B:])
+        nle, kl, mse, bo, bp, bs, l1 = V.VaeGan.loss(x, x_tilde, *dl, *dc, mus, logvar, targets, params)
+        ld = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+        ls = [F.mse_loss(x, x_tilde), torch.sum(kl) + torch.sum(mse), torch.sum(1e-6 * mse) - (1.0 - 1e-6) * ld, ld, l1]
+        term = torch.autograd.grad(ld, list(net.parameters()), retain_graph=True, allow_unused=True)
+        if fused:
+            V.VaeGan.backward_all(*ls)
+        else:
+            for i, l in enumerate(ls):
+                l.backward(retain_graph=i + 1 < len(ls))
+        grads.append(([p.grad.clone() for p in net.parameters()], term))
+    (ga, term), (gb, _) = grads
+    for (n, _), a, b, tm in zip(net.named_parameters(), ga, gb, term):
+        slack = 0.0 if tm is None else 2e-5 * tm.abs().max().item()
+        d = (a - b).abs().max().item()
+        assert d <= 2e-5 * a.abs().max().item() + slack + 1e-12, f"{n}: {d}"
+
+
+def test_vaegan_eval_branches():
+    """models/networks.py:248-258: x=None samples gen_size images; eval with x returns (x_tilde, params)."""
+    import vae_play_amd as V
+    net = V.VaeGan(32, 16).to(DEV).eval()
+    with torch.no_grad():
+        x_p = net(None, gen_size=3)
+        assert tuple(x_p.shape) == (3, 1, 32, 32) and float(x_p.min()) >= 0.0 and float(x_p.max()) <= 1.0
+        x_tilde, params = net(torch.rand(2, 1, 32, 32, device=DEV))
+        assert tuple(x_tilde.shape) == (2, 1, 32, 32) and tuple(params.shape) == (2, 3)

@@ -1,0 +1,95 @@
+"""Throughput of the VAE-GAN training step on the drop-in modules: VaeGan forward, VaeGan.loss,
+the five losses of train.py:61-66, five backward passes over one graph, four flat-arena RMSprop steps.
+usage: python tools/bench_vaegan.py [--img 128] [--z 128] [--batch 16] [--steps 10] [--cpu-steps 1]
+Prints one JSON line; `cpu_baseline` is the oracle restatement on this host's CPU (test infrastructure)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def step(net, opts, x, targets, eps, z_p, V, lam, fused=True):
+    B = x.size(0)
+    x_tilde, disc_class, disc_layer, mus, logvar, params = net(x, eps=eps, z_p=z_p)
+    dl = (disc_layer[:B], disc_layer[B:-B], disc_layer[-B:])
+    dc = (disc_class[:B], disc_class[B:-B], disc_class[-B:])
+    nle, kl, mse, bo, bp, bs, l1 = V.VaeGan.loss(x, x_tilde, *dl, *dc, mus, logvar, targets, params)
+    loss_recon = F.mse_loss(x, x_tilde)
+    loss_encoder = torch.sum(kl) + torch.sum(mse)
+    loss_disc = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
+    loss_decoder = torch.sum(lam * mse) - (1.0 - lam) * loss_disc
+    for o in opts:
+        o.zero_grad()
+    if fused:
+        V.VaeGan.backward_all(loss_recon, loss_encoder, loss_decoder, loss_disc, l1)
+    else:
+        loss_recon.backward(retain_graph=True)
+        loss_encoder.backward(retain_graph=True)
+        loss_decoder.backward(retain_graph=True)
+        loss_disc.backward(retain_graph=True)
+        l1.backward()
+    for o in opts:
+        o.step()
+    return loss_encoder
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--img", type=int, default=128)
+    ap.add_argument("--z", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--five-pass", action="store_true", help="the reference's five backward(retain_graph=True) calls instead of one")
+    a = ap.parse_args()
+    import vae_play_amd as V
+    from vae_play_amd import optim
+    dev = "cuda"
+    torch.manual_seed(0)
+    net = V.VaeGan(a.img, a.z).to(dev).train()
+    opts = [optim.RMSprop(m.parameters(), lr=1e-4) for m in (net.encoder, net.decoder, net.discriminator, net.param_encoder)]
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(a.batch, 1, a.img, a.img, generator=g).to(dev)
+    targets = torch.rand(a.batch, 3, generator=g).to(dev)
+    eps = torch.randn(a.batch, a.z, generator=g).to(dev)
+    z_p = torch.randn(a.batch, a.z, generator=g).to(dev)
+    for _ in range(a.warmup):
+        step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    out = {"metric": "images/sec (VAE-GAN train step, train.py:43-78)", "value": round(a.batch / dt, 1), "unit": "images/sec",
+           "ms_per_step": round(dt * 1e3, 3), "config": {"workload": f"VaeGan {a.img}x{a.img}x1 z={a.z} batch {a.batch}",
+                                                         "path": "autograd modules on HIP kernels (fp32 MFMA)",
+                                                         "backward": "five passes (train.py:69-73)" if a.five_pass else "one pass over the summed losses"},
+           "loss_encoder": float(loss)}
+    if a.cpu_steps > 0:
+        from oracle import ref_cpu as O
+        from oracle import ref_vaegan as G
+        torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+        p = G.init_vaegan_params(a.img, a.z, seed=0)
+        O.require_grad(p)
+        o_opts = G.make_optimizers(p)
+        xc, tc, ec, zc = x.cpu(), targets.cpu(), eps.cpu(), z_p.cpu()
+        G.train_step(p, o_opts, xc, tc, ec, zc, a.img)
+        t0 = time.perf_counter()
+        for _ in range(a.cpu_steps):
+            G.train_step(p, o_opts, xc, tc, ec, zc, a.img)
+        ct = (time.perf_counter() - t0) / a.cpu_steps
+        out["cpu_baseline"] = {"value": round(a.batch / ct, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{a.cpu_steps} step(s) after 1 warm-up"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

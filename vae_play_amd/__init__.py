@@ -4,9 +4,10 @@ HIP kernels behind a C ABI (include/vaeplay_hip.h), flat-arena optimiser, data-p
 Importing the package does not touch the GPU; using any op without libvaeplay_hip.so raises.
 """
 from . import _lib  # noqa: F401
-from .networks import (VAE, Decoder, DecoderBlock, Encoder, EncoderBlock, init_parameters,  # noqa: F401
-                       reparameterize)
+from .networks import (VAE, Decoder, DecoderBlock, DirectDecoder, Discriminator, Encoder, EncoderBlock,  # noqa: F401
+                       VaeGan, init_parameters, reparameterize)
 from .functional import binary_cross_entropy, kl_divergence, vae_loss  # noqa: F401
 
-__all__ = ["VAE", "Encoder", "Decoder", "EncoderBlock", "DecoderBlock", "reparameterize", "init_parameters",
+__all__ = ["VAE", "VaeGan", "Encoder", "Decoder", "Discriminator", "DirectDecoder", "EncoderBlock", "DecoderBlock",
+           "reparameterize", "init_parameters",
            "binary_cross_entropy", "kl_divergence", "vae_loss"]

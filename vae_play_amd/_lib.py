@@ -63,6 +63,9 @@ SIGNATURES = {
     "vp_bce_bwd_f32": (c_int, [P, P, P, c_float, P, c_size_t, P]),
     "vp_bce_sigmoid_bwd_f32": (c_int, [P, P, c_float, P, c_size_t, P]),
     "vp_sum_f32": (c_int, [P, c_size_t, P, P, c_size_t, P]),
+    "vp_half_sqdiff_f32": (c_int, [P, P, P, c_size_t, P]),
+    "vp_half_sqdiff_rowsum_f32": (c_int, [P, P, P, c_int, c_int, P]),
+    "vp_half_sqdiff_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "vp_adam_f32": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "vp_rmsprop_f32": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),
 }

@@ -128,6 +128,46 @@ __global__ void reduce_final_kernel(const float* __restrict__ part, int nblocks,
   if (threadIdx.x == 0) out[0] = (float)acc;
 }
 
+
+// ---- 0.5*(a-b)^2: per element (VaeGan.loss "nle", models/networks.py:267) and summed per row (":273", the
+// feature-matching term between discriminator layers) ------------------------------------------------------
+__global__ void half_sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    out[i] = 0.5f * d * d;
+  }
+}
+
+// one workgroup per row: 256 lanes stride the row, fp32 lane partials, fp64 cross-lane tree (bit-reproducible)
+__global__ void __launch_bounds__(256) half_sqdiff_rowsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 float* __restrict__ out, int n) {
+  __shared__ double sh[4];
+  const size_t base = (size_t)blockIdx.x * n;
+  float s0 = 0.f, s1 = 0.f;
+  int j = threadIdx.x;
+  for (; j + 256 < n; j += 512) {
+    const float d0 = a[base + j] - b[base + j], d1 = a[base + j + 256] - b[base + j + 256];
+    s0 += 0.5f * d0 * d0;
+    s1 += 0.5f * d1 * d1;
+  }
+  if (j < n) { const float d0 = a[base + j] - b[base + j]; s0 += 0.5f * d0 * d0; }
+  const double w = wave_sum_d((double)s0 + (double)s1);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+// da = g * (a - b), db = -da with g per element (per_row = 0) or per row (per_row = 1)
+__global__ void half_sqdiff_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                                       float* __restrict__ da, float* __restrict__ db, size_t total, int n, int per_row) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float gv = per_row ? g[i / (size_t)n] : g[i];
+    const float d = gv * (a[i] - b[i]);
+    if (da) da[i] = d;
+    if (db) db[i] = -d;
+  }
+}
+
 inline unsigned reduce_blocks(size_t n) { return grid_for(n / 4 + 1, 256, 1024); }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ gptr,
@@ -385,6 +425,27 @@ int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, 
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, (int)nb, out);
   return check_launch("vp_sum_f32(final)");
+}
+
+int vp_half_sqdiff_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream) {
+  VP_REQUIRE(a && b && out && n > 0, "vp_half_sqdiff_f32: bad arguments");
+  hipLaunchKernelGGL(half_sqdiff_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  return check_launch("vp_half_sqdiff_f32");
+}
+
+int vp_half_sqdiff_rowsum_f32(const float* a, const float* b, float* out, int R, int n_per_row, vp_stream stream) {
+  VP_REQUIRE(a && b && out && R > 0 && n_per_row > 0, "vp_half_sqdiff_rowsum_f32: bad arguments");
+  hipLaunchKernelGGL(half_sqdiff_rowsum_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, a, b, out, n_per_row);
+  return check_launch("vp_half_sqdiff_rowsum_f32");
+}
+
+int vp_half_sqdiff_bwd_f32(const float* a, const float* b, const float* g, float* da, float* db, int R, int n_per_row,
+                           int g_per_row, vp_stream stream) {
+  VP_REQUIRE(a && b && g && (da || db) && R > 0 && n_per_row > 0, "vp_half_sqdiff_bwd_f32: bad arguments");
+  const size_t total = (size_t)R * n_per_row;
+  hipLaunchKernelGGL(half_sqdiff_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a, b, g, da, db, total,
+                     n_per_row, g_per_row ? 1 : 0);
+  return check_launch("vp_half_sqdiff_bwd_f32");
 }
 
 int vp_bce_bwd_f32(const float* p, const float* t, const float* gptr, float gscale, float* dp, size_t n, vp_stream stream) {

@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(256) wgrad_narrow_big_kernel(const float* __re
   const int lane = threadIdx.x & 63;
   const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = blockIdx.y * 64 + lane;
+  const bool c_ok = c < Cs;                 // Cs need only be a multiple of 32: the upper half-wave then idles
   const int Hb = H * stride, Wb = W * stride;
   float acc[kTaps][NB];
 #pragma unroll
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) wgrad_narrow_big_kernel(const float* __re
   const int row1 = min(nrows, row0 + rows_per_block);
   for (int row = row0 + g; row < row1; row += 4) {
     const int b = row / H, h = row - b * H;
-    const float* sp = small + (size_t)row * W * Cs + c;
+    const float* sp = small + (size_t)row * W * Cs + (c_ok ? c : 0);
     const int hb0 = stride * h - 2 + r0, hb1 = stride * h - 2 + r1;
     const bool rok0 = has0 && hb0 >= 0 && hb0 < Hb, rok1 = has1 && hb1 >= 0 && hb1 < Hb;
     const float* base0 = big + ((size_t)(b * Hb + (rok0 ? hb0 : 0)) * Wb) * NB;
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(256) wgrad_narrow_big_kernel(const float* __re
       const int col0 = stride * x - 2 + e0 / NB, col1 = stride * x - 2 + e1 / NB;
       v0 = (rok0 && col0 >= 0 && col0 < Wb) ? base0[(size_t)col0 * NB + e0 % NB] : 0.f;
       v1 = (rok1 && col1 >= 0 && col1 < Wb) ? base1[(size_t)col1 * NB + e1 % NB] : 0.f;
-      dyv = sp[(size_t)x * Cs];
+      dyv = c_ok ? sp[(size_t)x * Cs] : 0.f;
     };
     float v0, v1, dyv;
     win(0, v0, v1, dyv);
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(256) wgrad_narrow_big_kernel(const float* __re
     for (int i = g; i < 5 * NB; i += 4) {
       const float v = (red[0][i][lane] + red[1][i][lane]) + (red[2][i][lane] + red[3][i][lane]);
       const int q = i / NB, n = i - q * NB;
-      dst[((size_t)(r * 5 + q) * Cs + c) * NB + n] = v;
+      if (c_ok) dst[((size_t)(r * 5 + q) * Cs + c) * NB + n] = v;
     }
   }
 }
@@ -312,7 +313,7 @@ static int narrow_rows_per_block(const ConvGeom& g) {
 int narrow_wgrad_kind(const ConvGeom& g) {
   if (g.ks != 5 || g.Hb != g.Hs * g.stride || g.Wb != g.Ws * g.stride) return 0;
   if (g.stride == 1 && (g.Cs == 1 || g.Cs == 3) && g.Cb % 64 == 0) return 1;   // narrow small side
-  if ((g.Cb == 1 || g.Cb == 3) && g.Cs % 64 == 0) return 2;                     // narrow big side
+  if ((g.Cb == 1 || g.Cb == 3) && g.Cs % 32 == 0) return 2;                     // narrow big side
   return 0;
 }
 
@@ -338,7 +339,7 @@ int narrow_wgrad_launch(const float* big, const float* small, float* dw_ref, con
     else
       hipLaunchKernelGGL((wgrad_narrow_small_kernel<1>), grid, dim3(256), 0, s, big, small, ws, g.B, g.Hs, g.Ws, g.Cb, nunits);
   } else {
-    dim3 grid(nblk, g.Cs / 64);
+    dim3 grid(nblk, (g.Cs + 63) / 64);
     if (g.Cb == 3)
       hipLaunchKernelGGL((wgrad_narrow_big_kernel<3>), grid, dim3(256), 0, s, big, small, ws, g.B, g.Hs, g.Ws, g.Cs, g.stride, rpb);
     else

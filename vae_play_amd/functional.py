@@ -312,6 +312,23 @@ class _BCESum(Function):
         return ops.bce_bwd(p, t, g.reshape(1).contiguous(), 1.0), None
 
 
+class _HalfSqDiff(Function):
+    """0.5*(a-b)^2 per element ("nle", models/networks.py:267) or summed over all but the first dim (":273")."""
+
+    @staticmethod
+    def forward(ctx, a, b, rowsum: bool):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.rowsum = rowsum
+        ctx.save_for_backward(a, b)
+        return ops.half_sqdiff_rowsum(a, b) if rowsum else ops.half_sqdiff(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da, db = ops.half_sqdiff_bwd(a, b, g.contiguous(), ctx.rowsum, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return da, db, None
+
+
 # ---- public functional API ----------------------------------------------------------------------
 def conv5x5(x, weight, bias=None, stride: int = 2, act: Optional[str] = None):
     return _Conv5.apply(x, weight, bias, stride, ACT_CODES[act])
@@ -381,6 +398,16 @@ def binary_cross_entropy(p, t, reduction: str = "sum"):
     if reduction == "mean":
         return s / p.numel()
     raise ValueError("reduction must be 'sum' or 'mean'")
+
+
+def half_sq_diff(a, b):
+    """0.5 * (a - b) ** 2, elementwise."""
+    return _HalfSqDiff.apply(a, b, False)
+
+
+def half_sq_diff_rowsum(a, b):
+    """torch.sum(0.5 * (a - b) ** 2, 1) for 2-D a, b."""
+    return _HalfSqDiff.apply(a, b, True)
 
 
 def vae_loss(x, x_tilde, mu, logvar):

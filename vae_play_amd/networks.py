@@ -10,6 +10,8 @@ reference; outputs are channels_last in memory.
   EncoderBlock  <- models/networks.py:10-30      Encoder <- models/networks.py:49-81
   DecoderBlock  <- models/networks.py:34-46      Decoder <- models/networks.py:84-115
   reparameterize <- models/networks.py:228-231   init_parameters <- models/networks.py:214-226
+  DirectDecoder <- models/networks.py:118-148    Discriminator <- models/networks.py:151-198
+  VaeGan        <- models/networks.py:201-281 (forward, loss); training idiom train.py:43-78
 """
 from __future__ import annotations
 
@@ -196,6 +198,140 @@ def init_parameters(*modules: nn.Module) -> None:
                     nn.init.uniform_(m.weight, -scale, scale)
                 if m.bias is not None and m.bias.requires_grad:
                     nn.init.constant_(m.bias, 0.0)
+
+
+class DirectDecoder(nn.Module):
+    """models/networks.py:118-148: a chain of bias-ed Linear layers WITHOUT activations (head 4, r_fc 2, xy_fc 2);
+    returns cat([r, xy], -1) of shape (B, 3)."""
+
+    def __init__(self, z_size, num_of_param=3):
+        super().__init__()
+        self.head = nn.Sequential(LinearParams(z_size, 512), LinearParams(512, 256), LinearParams(256, 128),
+                                  LinearParams(128, 64))
+        self.r_fc = nn.Sequential(LinearParams(64, 32), LinearParams(32, 1))
+        self.xy_fc = nn.Sequential(LinearParams(64, 32), LinearParams(32, 2))
+
+    def forward(self, ten):
+        ten = self.head(ten)
+        return torch.cat([self.r_fc(ten), self.xy_fc(ten)], dim=-1)
+
+
+class _ReluConv(nn.Sequential):
+    """Child "0" holds Conv2d(k5, s1, p2, bias)'s parameters (key ``conv.0.0.*``); child "1" of the reference is the
+    parameter-free ReLU.  The conv runs on the MFMA kernel, bias in its epilogue, ReLU as one elementwise pass."""
+
+    def forward(self, x):
+        return F_hip.activation(self[0](x), "relu")
+
+
+class Discriminator(nn.Module):
+    """models/networks.py:151-198.  ``forward(orig, predicted, sampled, mode)`` concatenates the three batches,
+    mode "REC" returns the flattened PRE-BatchNorm output of conv[recon_level] (NCHW order), mode "GAN" the
+    sigmoid score (3B, 1).  The attribute is spelled ``recon_levl`` as in the reference."""
+
+    def __init__(self, channel_in=3, recon_level=3, iter_level=3):
+        super().__init__()
+        self.size = channel_in
+        self.recon_levl = recon_level
+        self.conv = nn.ModuleList()
+        self.conv.append(_ReluConv(Conv5x5Params(32, self.size, bias=True, stride=1, transposed=False)))
+        self.size = 32
+        channel_out = self.size * 2
+        for _ in range(iter_level):
+            self.conv.append(EncoderBlock(channel_in=self.size, channel_out=channel_out))
+            self.size = channel_out
+            channel_out *= 2
+        # fc.0 / fc.1 / fc.3 carry the reference's keys; BN1d + ReLU (fc.1, fc.2) run as one fused kernel
+        self.fc = nn.Sequential(LinearParams(8 * 8 * self.size, 512, bias=False),
+                                BatchNormAct(512, momentum=BN_MOMENTUM, act="relu"),
+                                nn.Identity(),
+                                LinearParams(512, 1))
+
+    def forward(self, ten_orig, ten_predicted, ten_sampled, mode="REC"):
+        ten = torch.cat((ten_orig, ten_predicted, ten_sampled), 0)
+        if mode == "REC":
+            for i, lay in enumerate(self.conv):
+                if i == self.recon_levl:
+                    ten, layer_ten = lay(ten, True)
+                    return F_hip.flatten_nchw(layer_ten)
+                ten = lay(ten)
+            return None  # recon_level beyond the stack: the reference falls off the loop too
+        for lay in self.conv:
+            ten = lay(ten)
+        ten = F_hip.flatten_nchw(ten)
+        return F_hip.activation(self.fc(ten), "sigmoid")
+
+
+class VaeGan(nn.Module):
+    """models/networks.py:201-281: Encoder(channel_in=1) / Decoder(channel_out=1) / Discriminator / DirectDecoder.
+
+    ``forward`` follows the reference (training: x_tilde, disc_class, disc_layer, mus, log_variances, params;
+    eval: x_p for ``x is None`` else (x_tilde, params)); the two random draws may be injected with ``eps=`` (the
+    reparameterisation noise) and ``z_p=`` (the prior sample) for parity tests, and are taken from torch's device
+    RNG otherwise."""
+
+    def __init__(self, img_size, z_size=128, num_of_param=3):
+        super().__init__()
+        self.iter_level = int(math.log2(img_size // 8))
+        self.z_size = z_size
+        self.encoder = Encoder(channel_in=1, z_size=self.z_size, iter_level=self.iter_level)
+        self.decoder = Decoder(z_size=self.z_size, size=self.encoder.size, channel_out=1, iter_level=self.iter_level)
+        self.discriminator = Discriminator(channel_in=1, recon_level=self.iter_level, iter_level=self.iter_level)
+        self.param_encoder = DirectDecoder(z_size, num_of_param=num_of_param)
+        self.init_parameters()
+
+    def init_parameters(self):
+        init_parameters(self)
+
+    def reparameterize(self, mu, logvar, eps=None):
+        return reparameterize(mu, logvar, eps=eps)
+
+    def forward(self, x, gen_size=10, *, eps=None, z_p=None):
+        dev = next(self.parameters()).device
+        if self.training:
+            mus, log_variances = self.encoder(x)
+            z = self.reparameterize(mus, log_variances, eps)
+            x_tilde = self.decoder(z)
+            params = self.param_encoder(z)
+            if z_p is None:
+                z_p = torch.randn(len(x), self.z_size, device=dev)
+            z_p = z_p.detach().requires_grad_(True)
+            x_p = self.decoder(z_p)
+            disc_layer = self.discriminator(x, x_tilde, x_p, "REC")
+            disc_class = self.discriminator(x, x_tilde, x_p, "GAN")
+            return x_tilde, disc_class, disc_layer, mus, log_variances, params
+        if x is None:
+            if z_p is None:
+                z_p = torch.randn(gen_size, self.z_size, device=dev)
+            return self.decoder(z_p)
+        mus, log_variances = self.encoder(x)
+        z = self.reparameterize(mus, log_variances, eps)
+        return self.decoder(z), self.param_encoder(z)
+
+    @staticmethod
+    def backward_all(*losses, retain_graph: bool = False):
+        """One traversal of the graph for train.py:69-73's five ``backward(retain_graph=True)`` calls: gradients
+        accumulate, so the result is the gradient of the SUM of the losses (identical up to fp32 summation order)
+        at a fifth of the backward kernel time."""
+        total = losses[0]
+        for l in losses[1:]:
+            total = total + l
+        total.backward(retain_graph=retain_graph)
+
+    @staticmethod
+    def loss(x, x_tilde, disc_layer_original, disc_layer_predicted, disc_layer_sampled, disc_class_original,
+             disc_class_predicted, disc_class_sampled, mus, variances, targets, params):
+        """models/networks.py:265-281, same 7 return values.  The per-pixel / per-feature terms (nle, mse) and the
+        KL run on HIP kernels; the terms over O(B) elements (three -log(p + 1e-3) and the smooth-L1 over (B, 3))
+        are torch elementwise ops on the same device."""
+        nle = F_hip.half_sq_diff(x.reshape(len(x), -1), x_tilde.reshape(len(x_tilde), -1))
+        kl = F_hip.kl_divergence(mus, variances)
+        mse = F_hip.half_sq_diff_rowsum(disc_layer_original, disc_layer_predicted)
+        bce_dis_original = -torch.log(disc_class_original + 1e-3)
+        bce_dis_predicted = -torch.log(1 - disc_class_predicted + 1e-3)
+        bce_dis_sampled = -torch.log(1 - disc_class_sampled + 1e-3)
+        l1_enc_param = torch.nn.functional.smooth_l1_loss(targets, params, reduction="sum") / x.size(0)
+        return nle, kl, mse, bce_dis_original, bce_dis_predicted, bce_dis_sampled, l1_enc_param
 
 
 class VAE(nn.Module):

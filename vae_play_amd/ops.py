@@ -269,6 +269,27 @@ def bce_sigmoid_bwd(p, t, gscale: float):
     return dl
 
 
+def half_sqdiff(a, b):
+    out = torch.empty_like(a)
+    _lib.call("vp_half_sqdiff_f32", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def half_sqdiff_rowsum(a, b):
+    R, n = a.shape[0], a.numel() // a.shape[0]
+    out = torch.empty(R, dtype=torch.float32, device=a.device)
+    _lib.call("vp_half_sqdiff_rowsum_f32", _p(a), _p(b), _p(out), R, n, _stream())
+    return out
+
+
+def half_sqdiff_bwd(a, b, g, per_row: bool, want_a: bool = True, want_b: bool = True):
+    R, n = a.shape[0], a.numel() // a.shape[0]
+    da = torch.empty_like(a) if want_a else None
+    db = torch.empty_like(a) if want_b else None
+    _lib.call("vp_half_sqdiff_bwd_f32", _p(a), _p(b), _p(g), _p(da), _p(db), R, n, 1 if per_row else 0, _stream())
+    return da, db
+
+
 def tensor_sum(x):
     n = x.numel()
     ws = _ws(_lib.load().vp_reduce_workspace_bytes(n), x)

@@ -51,6 +51,22 @@ class FlatArena:
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
 
+    def gather_grads(self) -> None:
+        """Bring gradients that live outside the arena back into it.  ``module.zero_grad()`` (train.py:68) sets
+        ``.grad`` to None, after which autograd allocates fresh tensors: copy those in and re-point ``.grad``.
+        A parameter that received no gradient contributes zeros (torch would skip it; its state then differs)."""
+        base = self.flat_grad.data_ptr()
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat_grad[o:o + p.numel()].view_as(p)
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != base + 4 * o:
+                    view.copy_(p.grad)
+                else:
+                    continue
+                p.grad = view
+
 
 class _FlatOptimizer:
     def __init__(self, params, lr: float):
@@ -84,6 +100,7 @@ class Adam(_FlatOptimizer):
     def step(self) -> None:
         self.step_count += 1
         a = self.arena
+        a.gather_grads()
         ops.adam_step(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                       self.eps, self.step_count, self.grad_scale)
 
@@ -100,4 +117,5 @@ class RMSprop(_FlatOptimizer):
     def step(self) -> None:
         self.step_count += 1
         a = self.arena
+        a.gather_grads()
         ops.rmsprop_step(a.flat_param, a.flat_grad, self.square_avg, self.lr, self.alpha, self.eps, self.grad_scale)
