@@ -103,6 +103,16 @@ int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, 
                             int R, int C, int act, float slope, int batch_stats,
                             void* ws, size_t ws_bytes, vp_stream stream);
 int vp_nchw_to_nhwc_split_f32(const float* in, float* out, void* out_split, int B, int C, int H, int W, vp_stream stream);
+/* Every conv weight of a step in ONE launch: job i packs w (reference layout [Csmall][Cbig][5][5]) into p0
+ * ([Csmall][25][Cbig]) and/or p1 ([Cbig][25][Csmall_pad]); split != 0 writes bf16 hi/lo planes, else fp32.
+ * jobs is a HOST array (read during the call only); at most 32 output layouts per batch. */
+typedef struct vp_pack_job {
+  const float* w;
+  void* p0;
+  void* p1;
+  int Csmall, Cbig, Csmall_pad, split;
+} vp_pack_job;
+int vp_pack_w5_batch(const vp_pack_job* jobs, int njobs, vp_stream stream);
 /* edge layers (1/3 image channels) on the bf16x3 path: the small-channel dimension zero-padded to a multiple of 8.
  * p1_split = [Cbig][25][Csmall_pad] planes; dlogit_split = [npix][Cpad] planes next to the fp32 dlogit [npix][C]. */
 int vp_pack_w5_p1_split_padded(const float* w_ref, void* p1_split, int Csmall, int Cbig, int Csmall_pad, vp_stream stream);

@@ -15,6 +15,13 @@ LIB_PATH = os.path.join(_HERE, "libvaeplay_hip.so")
 
 P = c_void_p  # device pointers / stream
 
+
+class PackJob(ctypes.Structure):
+    """vp_pack_job of include/vaeplay_hip.h (one weight tensor of vp_pack_w5_batch)."""
+    _fields_ = [("w", c_void_p), ("p0", c_void_p), ("p1", c_void_p), ("Csmall", c_int), ("Cbig", c_int),
+                ("Csmall_pad", c_int), ("split", c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/vaeplay_hip.h one to one
 SIGNATURES = {
     "vp_abi_version": (c_int, []),
@@ -41,6 +48,7 @@ SIGNATURES = {
     "vp_bn_act_bwd_split_f32": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, c_size_t, P]),
     "vp_nchw_to_nhwc_split_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "vp_pack_w5_p1_split_padded": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "vp_pack_w5_batch": (c_int, [ctypes.POINTER(PackJob), c_int, P]),
     "vp_bce_sigmoid_bwd_pad_split_f32": (c_int, [P, P, c_float, P, P, c_size_t, c_int, c_int, P]),
     "vp_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vp_gemm_f32": (c_int, [P, c_long, c_long, P, c_long, c_long, P, c_int, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),

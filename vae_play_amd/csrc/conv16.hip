@@ -70,6 +70,61 @@ static int pack_w5_launch(const float* w, void* p0, void* p1, int Cs, int Cb, hi
   return check_launch(what);
 }
 
+// ---- all conv weights of a step in ONE launch -------------------------------------------------------------
+// A step re-packs ~10 weight tensors into 1-2 layouts each: 15-20 launches of 7-9 us whose cost is launch latency,
+// not bytes.  The batch kernel walks a job table passed by value: job = (tensor, layout, fp32|split), blockIdx.x
+// is a tile index into the concatenation of all jobs' tiles.
+constexpr int kMaxPackJobs = 32;
+struct PackJob { const float* w; void* out; int Cs, Cb, CsP, mode, split, tile_begin; };
+struct PackTable { PackJob j[kMaxPackJobs]; int n; };
+
+template <int MODE, bool SPLIT>
+__device__ __forceinline__ void pack_tile(float (*tile)[kTaps + 1], const float* __restrict__ w, void* __restrict__ outv, int Cs,
+                                          int Cb, int CsP, int fixed, int j0) {
+  constexpr int nt = kTaps;
+  const size_t n = (size_t)(MODE == 1 ? CsP : Cs) * Cb * nt;
+  const int lim = (MODE == 0 ? Cb : Cs) - j0, lim_out = (MODE == 0 ? Cb : CsP) - j0;
+  for (int idx = threadIdx.x; idx < 64 * nt; idx += 256) {
+    const int j = idx / nt, t = idx - j * nt;
+    if (j < lim) tile[j][t] = w[MODE == 0 ? ((size_t)fixed * Cb + j0 + j) * nt + t : ((size_t)(j0 + j) * Cb + fixed) * nt + t];
+  }
+  __syncthreads();
+  const int inner = MODE == 0 ? Cb : CsP;
+  for (int idx = threadIdx.x; idx < 64 * nt; idx += 256) {
+    const int t = idx >> 6, j = idx & 63;
+    if (j < lim_out) {
+      const size_t o = ((size_t)fixed * nt + t) * inner + j0 + j;
+      const float v = j < lim ? tile[j][t] : 0.f;
+      if constexpr (SPLIT) {
+        u16_t h, l;
+        split_f32(v, h, l);
+        ((u16_t*)outv)[o] = h;
+        ((u16_t*)outv)[n + o] = l;
+      } else {
+        ((float*)outv)[o] = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) pack_w5_batch_kernel(const PackTable tab) {
+  __shared__ float tile[64][kTaps + 1];
+  int ji = 0;
+  for (int k = 1; k < tab.n; ++k)
+    if ((int)blockIdx.x >= tab.j[k].tile_begin) ji = k;     // tile_begin is increasing: the last job that starts at or before us
+  const PackJob& jb = tab.j[ji];
+  const int tl = blockIdx.x - jb.tile_begin;
+  const int ntile = ((jb.mode == 0 ? jb.Cb : jb.CsP) + 63) / 64;
+  const int fixed = tl / ntile, j0 = (tl - fixed * ntile) * 64;
+  if (jb.mode == 0) {
+    if (jb.split) pack_tile<0, true>(tile, jb.w, jb.out, jb.Cs, jb.Cb, jb.CsP, fixed, j0);
+    else pack_tile<0, false>(tile, jb.w, jb.out, jb.Cs, jb.Cb, jb.CsP, fixed, j0);
+  } else {
+    if (jb.split) pack_tile<1, true>(tile, jb.w, jb.out, jb.Cs, jb.Cb, jb.CsP, fixed, j0);
+    else pack_tile<1, false>(tile, jb.w, jb.out, jb.Cs, jb.Cb, jb.CsP, fixed, j0);
+  }
+}
+
 int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hipStream_t s, int nt) {
   return pack_w5_launch<false>(w, p0, p1, Cs, Cb, s, "vp_pack_w_f32", 0, nt);
 }
@@ -97,6 +152,31 @@ int vp_pack_w5_split(const float* w_ref, void* p0_split, void* p1_split, int Csm
   VP_REQUIRE(w_ref && (p0_split || p1_split) && Csmall > 0 && Cbig > 0, "vp_pack_w5_split: bad arguments");
   VP_REQUIRE(Csmall <= 65535 && Cbig <= 65535, "vp_pack_w5_split: channel count too large");
   return pack_w5_launch<true>(w_ref, p0_split, p1_split, Csmall, Cbig, (hipStream_t)stream, "vp_pack_w5_split");
+}
+
+int vp_pack_w5_batch(const vp_pack_job* jobs, int njobs, vp_stream stream) {
+  VP_REQUIRE(jobs && njobs > 0, "vp_pack_w5_batch: bad arguments");
+  PackTable tab;
+  tab.n = 0;
+  int tiles = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const vp_pack_job& q = jobs[i];
+    VP_REQUIRE(q.w && (q.p0 || q.p1) && q.Csmall > 0 && q.Cbig > 0, "vp_pack_w5_batch: job %d: bad arguments", i);
+    VP_REQUIRE(q.Csmall <= 65535 && q.Cbig <= 65535, "vp_pack_w5_batch: job %d: channel count too large", i);
+    const int CsP = q.Csmall_pad > q.Csmall ? q.Csmall_pad : q.Csmall;
+    VP_REQUIRE(CsP == q.Csmall || (q.split && CsP % 8 == 0), "vp_pack_w5_batch: job %d: padding needs split planes and a multiple of 8", i);
+    for (int mode = 0; mode < 2; ++mode) {
+      void* out = mode == 0 ? q.p0 : q.p1;
+      if (!out) continue;
+      VP_REQUIRE(tab.n < kMaxPackJobs, "vp_pack_w5_batch: more than %d layouts in one batch", kMaxPackJobs);
+      PackJob& j = tab.j[tab.n++];
+      j.w = q.w; j.out = out; j.Cs = q.Csmall; j.Cb = q.Cbig; j.CsP = mode == 1 ? CsP : q.Csmall; j.mode = mode;
+      j.split = q.split ? 1 : 0; j.tile_begin = tiles;
+      tiles += mode == 0 ? q.Csmall * ((q.Cbig + 63) / 64) : q.Cbig * ((CsP + 63) / 64);
+    }
+  }
+  hipLaunchKernelGGL(pack_w5_batch_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, tab);
+  return check_launch("vp_pack_w5_batch");
 }
 
 int vp_pack_w5_p1_split_padded(const float* w_ref, void* p1_split, int Csmall, int Cbig, int Csmall_pad, vp_stream stream) {

@@ -40,6 +40,11 @@ class _Plan:
         a = list(args) + [None]  # last argument of every entry point is the stream
         self.calls.append([name, fn, a, len(a) - 1, flops, tag])
 
+    def add_first(self, name: str, *args):
+        fn = getattr(_lib.load(), name)
+        a = list(args) + [None]
+        self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, ""])
+
     def run(self, stream_ptr: int, timers: Optional[dict] = None):
         s = c_void_p(stream_ptr)
         for name, fn, a, slot, flops, tag in self.calls:
@@ -112,6 +117,11 @@ class FusedVAEStep:
         mom, eps_bn = 0.9, 1e-5
         fwd, bwd = _Plan(), _Plan()
         P = _ptr
+        pack_jobs = []   # every conv weight is re-packed by ONE launch at the head of the forward plan
+
+        def pack(weight, p0, p1, Cs, Cb, split, Cs_pad=0):
+            pack_jobs.append(_lib.PackJob(weight.data_ptr(), p0.data_ptr() if p0 is not None else None,
+                                          p1.data_ptr() if p1 is not None else None, Cs, Cb, Cs_pad, 1 if split else 0))
 
         def grad_of(p: torch.nn.Parameter) -> torch.Tensor:
             if p.grad is None:
@@ -161,13 +171,13 @@ class FusedVAEStep:
             if enc16[i]:
                 p0 = self._sbuf(f"enc{i}.p0s", Cout * 25 * Cin)
                 p1 = self._sbuf(f"enc{i}.p1s", Cin * 25 * Cout)
-                fwd.add("vp_pack_w5_split", P(blk.conv.weight), P(p0), P(p1), Cout, Cin)
+                pack(blk.conv.weight, p0, p1, Cout, Cin, True)
                 fwd.add("vp_conv5_gather_bf16x3", P(enc_in_s[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
                         flops=fl, tag=f"enc{i}.fwd")
             else:
                 p0 = self._buf(f"enc{i}.p0", Cout * 25 * Cin)
                 p1 = self._buf(f"enc{i}.p1", Cin * 25 * Cout) if i > 0 else None
-                fwd.add("vp_pack_w5_f32", P(blk.conv.weight), P(p0), P(p1), Cout, Cin)
+                pack(blk.conv.weight, p0, p1, Cout, Cin, False)
                 fwd.add("vp_conv5_gather_f32", P(enc_in[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
                         flops=fl, tag=f"enc{i}.fwd")
             # the activation feeds the next conv (+ its wgrad) or, for the last block, the flatten
@@ -221,13 +231,13 @@ class FusedVAEStep:
             if dec16[i]:
                 p1 = self._sbuf(f"dec{i}.p1s", Cout * 25 * Cin)   # T family: [Cbig=Cout][25][Csmall=Cin]
                 p0 = self._sbuf(f"dec{i}.p0s", Cin * 25 * Cout)   # F family (dgrad): [Csmall=Cin][25][Cbig=Cout]
-                fwd.add("vp_pack_w5_split", P(blk.conv.weight), P(p0), P(p1), Cin, Cout)
+                pack(blk.conv.weight, p0, p1, Cin, Cout, True)
                 fwd.add("vp_conv5_scatter_bf16x3", P(dec_in_s[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
                         flops=fl, tag=f"dec{i}.fwd")
             else:
                 p1 = self._buf(f"dec{i}.p1", Cout * 25 * Cin)
                 p0 = self._buf(f"dec{i}.p0", Cin * 25 * Cout)
-                fwd.add("vp_pack_w5_f32", P(blk.conv.weight), P(p0), P(p1), Cin, Cout)
+                pack(blk.conv.weight, p0, p1, Cin, Cout, False)
                 fwd.add("vp_conv5_scatter_f32", P(dec_in[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
                         flops=fl, tag=f"dec{i}.fwd")
             nxt16 = i + 1 < L and dec16[i + 1]
@@ -244,11 +254,11 @@ class FusedVAEStep:
         Cf = dec_ch[-1]
         fp0 = self._buf("fin.p0", C * 25 * Cf)
         fp1 = self._buf("fin.p1", Cf * 25 * C)
-        fwd.add("vp_pack_w5_f32", P(fin.weight), P(fp0), P(fp1), C, Cf)
+        pack(fin.weight, fp0, fp1, C, Cf, False)
         xt_nhwc = self._buf("xt_nhwc", B * S * S * C)
         if dec_in_s[-1] is not None:
             fp0s = self._sbuf("fin.p0s", C * 25 * Cf)
-            fwd.add("vp_pack_w5_split", P(fin.weight), P(fp0s), None, C, Cf)
+            pack(fin.weight, fp0s, None, C, Cf, True)
             fwd.add("vp_conv5_gather_bf16x3", P(dec_in_s[-1]), P(fp0s), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, 1, _ACT_SIGMOID,
                     flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
         else:
@@ -270,7 +280,7 @@ class FusedVAEStep:
         if fin16:
             dlogit_s = self._sbuf("g.dlogit_s", B * S * S * 8)
             fp1s = self._sbuf("fin.p1s", Cf * 25 * 8)
-            fwd.add("vp_pack_w5_p1_split_padded", P(fin.weight), P(fp1s), C, Cf, 8)
+            pack(fin.weight, None, fp1s, C, Cf, True, 8)
             bwd.add("vp_bce_sigmoid_bwd_pad_split_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), P(dlogit_s), B * S * S, C, 8)
         else:
             bwd.add("vp_bce_sigmoid_bwd_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), n_pix)
@@ -359,6 +369,8 @@ class FusedVAEStep:
                 if i > 0:
                     bwd.add("vp_conv5_scatter_f32", P(other), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
                             flops=fl, tag=f"enc{i}.dgrad")                                 # cur = d a_{i-1}
+        self._pack_jobs = (_lib.PackJob * len(pack_jobs))(*pack_jobs)   # host array read by every call: keep it alive
+        fwd.add_first("vp_pack_w5_batch", self._pack_jobs, len(pack_jobs))
         self._fwd, self._bwd_b = fwd, bwd
         self._bn_mods = [m for m in self.vae.modules() if hasattr(m, "num_batches_tracked")]
 
