@@ -45,9 +45,9 @@ class _Plan:
         a = list(args) + [None]
         self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, ""])
 
-    def run(self, stream_ptr: int, timers: Optional[dict] = None):
+    def run(self, stream_ptr: int, timers: Optional[dict] = None, start: int = 0, stop: Optional[int] = None):
         s = c_void_p(stream_ptr)
-        for name, fn, a, slot, flops, tag in self.calls:
+        for name, fn, a, slot, flops, tag in self.calls[start:stop]:
             a[slot] = s
             timed = timers is not None and name in timers["names"]
             if timed:
@@ -348,6 +348,8 @@ class FusedVAEStep:
 
         bn_block_bwd2(h, dhb_a, dh, B, 1024, fc_bn, h_mean, h_rstd, h_ws)
         bwd.add("vp_gemm_f32", P(dh), 1, 1024, P(flat), 1, F0, P(grad_of(fc_lin.weight)), F0, None, 1024, F0, B, 2, P(ws_g1), wsn)
+        # the encoder's dense gradients (fc.0 = 134 MB at config 3, fc.1, l_mu, l_var) are final here: second bucket
+        self._bwd_b_dense_done = len(bwd.calls)
         bwd.add("vp_gemm_f32", P(dh), 1024, 1, P(fc_lin.weight), 1, F0, P(gA), F0, None, B, F0, 1024, 1, P(ws_g1), wsn)
         bwd.add("vp_nchw_to_nhwc_f32", P(gA), P(gB), B, size, 8, 8)
         cur, other = gB, gA
@@ -385,7 +387,7 @@ class FusedVAEStep:
         return n
 
     # ---- execution ---------------------------------------------------------------------------
-    def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None):
+    def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None, on_dense_grads=None):
         s = torch.cuda.current_stream().cuda_stream
         self._fwd.run(s, timers)
         self._bwd_dec.run(s, timers)
@@ -393,10 +395,14 @@ class FusedVAEStep:
             on_decoder_grads()
         self._bwd_a.run(s, timers)
         self._dhb[0].add_(self._dhb[1])          # d hb = dgrad(mu head) + dgrad(logvar head)  (B x 1024)
-        self._bwd_b.run(s, timers)
+        self._bwd_b.run(s, timers, 0, self._bwd_b_dense_done)
+        if on_dense_grads is not None:
+            on_dense_grads()
+        self._bwd_b.run(s, timers, self._bwd_b_dense_done)
         torch.add(self.recon, self.kl_sum, out=self._loss_num)
 
-    def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None):
+    def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None,
+                         on_dense_grads=None):
         """Gradients of (BCE_sum + KL_sum)/B land in the optimiser's flat gradient arena.
         Returns (loss, recon, kl) as device scalars (no host sync).  ``timers`` =
         {"names": set of entry points, "events": []} brackets those launches with HIP events
@@ -405,10 +411,10 @@ class FusedVAEStep:
             self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
         self.x_nchw.copy_(x, non_blocking=True)
         self.eps.copy_(eps, non_blocking=True)
-        if self._graph is not None and timers is None and on_decoder_grads is None:
+        if self._graph is not None and timers is None and on_decoder_grads is None and on_dense_grads is None:
             self._graph.replay()
         else:
-            self._launch_all(timers, on_decoder_grads)
+            self._launch_all(timers, on_decoder_grads, on_dense_grads)
         # BatchNorm num_batches_tracked is advanced lazily in sync_counters()
         self._steps_since_sync = getattr(self, "_steps_since_sync", 0) + 1
         return self._loss_num / self.B, self.recon, self.kl_sum
@@ -431,21 +437,35 @@ class FusedVAEStep:
             "decoder parameters must form the tail of the flat arena"
         return first
 
+    def _encoder_dense_start(self) -> int:
+        """Arena offset of ``encoder.fc.0.weight``: the encoder's conv/BN parameters precede it, its dense
+        parameters (fc.0, fc.1, l_mu, l_var) run from there to the decoder slice."""
+        a = self.opt.arena
+        off = {id(p): o for p, o in zip(a.params, a.offsets)}
+        first = off[id(self.vae.encoder.fc[0].weight)]
+        conv_ids = {id(p) for p in self.vae.encoder.conv.parameters()}
+        assert all((id(p) in conv_ids) == (o < first) for p, o in zip(a.params, a.offsets) if o < self._decoder_slice_start()), \
+            "encoder conv parameters must form the head of the flat arena"
+        return first
+
     def step(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, overlap: bool = True):
         """One full training step: fwd + loss + bwd, SUM all-reduce of the flat gradient arena, fused update.
 
-        With several ranks the arena is reduced as two buckets of the same flat buffer: the decoder slice is
-        handed to RCCL as soon as the decoder's gradients are final (its all-reduce runs on the communicator's
-        stream underneath the rest of backward), the encoder slice after backward; the optimiser kernel waits
-        for both.  ``overlap=False`` issues one all-reduce of the whole arena after backward."""
+        With several ranks the arena is reduced as three buckets of the same flat buffer, each handed to RCCL as
+        soon as its gradients are final so that the all-reduce runs on the communicator's stream underneath the rest
+        of backward: the decoder slice after the decoder's backward, the encoder's dense slice (fc.0 is 134 MB of the
+        213 MB at config 3) after its weight gradient, and the encoder's conv slice (17 MB) after backward; the
+        optimiser kernel waits for all three.  ``overlap=False`` issues one all-reduce of the whole arena."""
         if self.world > 1 and overlap:
             g = self.opt.flat_grad
             cut = self._decoder_slice_start()
+            dense = self._encoder_dense_start()
             works = []
             out = self.forward_backward(
                 x, eps, timers,
-                on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)))
-            works.append(parallel.allreduce_flat_grads(g[:cut], self.group, async_op=True))
+                on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)),
+                on_dense_grads=lambda: works.append(parallel.allreduce_flat_grads(g[dense:cut], self.group, async_op=True)))
+            works.append(parallel.allreduce_flat_grads(g[:dense], self.group, async_op=True))
             for w in works:
                 if w is not None:
                     w.wait()
