@@ -184,6 +184,16 @@ int vp_bce_sum_f32(const float* p, const float* t, size_t n, float* out, void* w
 int vp_bce_bwd_f32(const float* p, const float* t, const float* gptr, float gscale, float* dp, size_t n, vp_stream stream);
 /* fused sigmoid+BCE backward on the logits: dlogit = gscale * (p - t) */
 int vp_bce_sigmoid_bwd_f32(const float* p, const float* t, float gscale, float* dlogit, size_t n, vp_stream stream);
+/* ---- segmentation loss of train_BE.py:58-59: bce_weight * F.binary_cross_entropy_with_logits(x, t) (mean over B*n)
+ * + compute_dice_loss(sigmoid(x), t, smooth) (tools/ops.py:12-19) for B samples of n logits each.
+ * fwd: loss[0] and sums[B][4] = {sum bce, sum p*t, sum p, sum t} per sample (kept for the backward);
+ * bwd: dlogits = g * d loss / d logits with g read from the device scalar gptr (NULL = 1). */
+size_t vp_be_loss_workspace_bytes(int B, int n);
+int vp_be_loss_fwd_f32(const float* logits, const float* targets, float* loss, float* sums, int B, int n, float bce_weight,
+                       float smooth, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_be_loss_bwd_f32(const float* logits, const float* targets, const float* sums, const float* gptr, float* dlogits, int B,
+                       int n, float bce_weight, float smooth, vp_stream stream);
+
 /* ---- 0.5*(a-b)^2 (VaeGan.loss, models/networks.py:267 "nle" per element, :273 "mse" summed per row) ---- */
 int vp_half_sqdiff_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream);
 /* out[r] = sum_j 0.5*(a[r][j]-b[r][j])^2 for R contiguous rows of n_per_row elements */

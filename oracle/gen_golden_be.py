@@ -1,0 +1,146 @@
+"""Generate tests/golden/be_*.npz: the networks_BE heads composed from the REAL reference's models/blocks.py classes
+(models/networks_BE.py itself needs torchvision and cannot be imported here) pin oracle/ref_be.py bit-for-bit.
+The loss terms come from torch (BCEWithLogits) and from the oracle's restatement of compute_dice_loss, whose
+parity is unpinned (tools/ops.py needs cv2) -- see oracle/ref_be.py.
+
+    python oracle/gen_golden_be.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_be as BE  # noqa: E402
+from oracle import ref_cpu as O  # noqa: E402
+from oracle.gen_golden import bit_equal, import_reference, np_  # noqa: E402
+
+
+def ref_masknet(blocks, in_channel):
+    """models/networks_BE.py:39-58 written with the reference's own blocks (attribute names = state_dict keys)."""
+    m = nn.Module()
+    m.conv1 = blocks.Up(in_channel, in_channel // 4, if_add_coord=True)
+    m.conv2 = blocks.Up(in_channel // 4, in_channel // 8, if_add_coord=True)
+    m.predictor = nn.Sequential(
+        blocks.Conv2d(in_channel // 8, in_channel // 4, 3, stride=1, bn=None, activate=None),
+        blocks.Conv2d(in_channel // 4, in_channel // 8, 3, stride=1, bn=None, activate=None),
+        blocks.Conv2d(in_channel // 8, 1, 3, stride=1, bn=None, activate=None))
+    m.run = lambda x: m.predictor(m.conv2(m.conv1(x)))
+    return m
+
+
+def heads_fixture(blocks, C, B, H, steps):
+    holder = nn.Module()
+    holder.mask_net = ref_masknet(blocks, C)
+    holder.edge_net = ref_masknet(blocks, C)
+    holder.load_state_dict(BE.seeded_weights(holder.state_dict(), 123))
+    holder.train()
+    g = torch.Generator().manual_seed(9)
+    feature = torch.randn(B, C, H, H, generator=g)
+    bimgs = (torch.rand(B, 1, 4 * H, 4 * H, generator=g) > 0.5).float()
+    eimgs = (torch.rand(B, 1, 4 * H, 4 * H, generator=g) > 0.8).float()
+    ropt = torch.optim.Adam(holder.parameters(), lr=1e-4)             # train_BE.py:131
+    p = {k: v.detach().clone() for k, v in holder.state_dict().items()}
+    O.require_grad(p)
+    oopt = O.make_optimizer(p, "adam", 1e-4)
+    fx = {"meta_C": C, "meta_B": B, "meta_H": H, "meta_steps": steps, "weight_seed": np.array(123),
+          "feature": np_(feature), "bimgs": np_(bimgs), "eimgs": np_(eimgs)}
+    for step in range(1, steps + 1):
+        ropt.zero_grad()
+        masks = holder.mask_net.run(feature)
+        edges = holder.edge_net.run(feature)
+        loss_edge = BE.be_loss(edges, eimgs)
+        loss_mask = BE.be_loss(masks, bimgs)
+        (loss_edge + loss_mask).backward()
+        ropt.step()
+        o = BE.heads_step(p, oopt, feature, bimgs, eimgs)
+        bit_equal(o["masks"], masks.detach(), f"masks step{step}")
+        bit_equal(o["edges"], edges.detach(), f"edges step{step}")
+        rsd = holder.state_dict(keep_vars=True)
+        for n in p:
+            bit_equal(p[n].detach(), rsd[n].detach(), f"param {n} step{step}")
+        if step == 1:
+            for n in O.trainable_names(p):
+                bit_equal(p[n].grad, rsd[n].grad, f"grad {n}")
+                fx[f"grad/{n}"] = np_(rsd[n].grad)
+            fx["masks"], fx["edges"] = np_(masks), np_(edges)
+            for n in p:
+                if "running" in n:
+                    fx[f"bn/{n}"] = np_(p[n])
+        fx[f"loss_edge{step}"] = np_(loss_edge.detach().double().reshape(1))
+        fx[f"loss_mask{step}"] = np_(loss_mask.detach().double().reshape(1))
+        for n in O.trainable_names(p):
+            fx[f"param{step}/{n}"] = np_(p[n])
+    return fx
+
+
+def aux_fixture(blocks, Cin, target, B, H):
+    layers = []
+    c = Cin
+    for _ in range(int(np.log2(Cin // target))):
+        layers.append(blocks.Conv2d(c, c // 2, 1, stride=1, bn="batch"))
+        layers.append(blocks.Conv2d(c // 2, c // 2, 3, stride=1, bn="batch"))
+        c //= 2
+    holder = nn.Module()
+    holder.aux_convs = nn.Sequential(*layers)
+    holder.load_state_dict(BE.seeded_weights(holder.state_dict(), 321))
+    holder.train()
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(B, Cin, H, H, generator=g, requires_grad=True)
+    y = holder.aux_convs(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    p = {k: v.detach().clone() for k, v in holder.state_dict().items()}
+    # the reference's forward already advanced its BN buffers: rewind ours to the initial state
+    for k in p:
+        if k.endswith("running_mean"):
+            p[k] = torch.zeros_like(p[k])
+        elif k.endswith("running_var"):
+            p[k] = torch.ones_like(p[k])
+        elif k.endswith("num_batches_tracked"):
+            p[k] = torch.zeros_like(p[k])
+    O.require_grad(p)
+    xo = x.detach().clone().requires_grad_(True)
+    yo = BE.aux_convs_forward(p, xo, Cin, target, True)
+    yo.backward(gy)
+    bit_equal(yo.detach(), y.detach(), "aux y")
+    bit_equal(xo.grad, x.grad, "aux dx")
+    rsd = holder.state_dict(keep_vars=True)
+    fx = {"meta_Cin": Cin, "meta_target": target, "weight_seed": np.array(321), "x": np_(x), "y": np_(y), "gy": np_(gy),
+          "dx": np_(x.grad)}
+    for n in O.trainable_names(p):
+        bit_equal(p[n].grad, rsd[n].grad, f"aux grad {n}")
+        fx[f"grad/{n}"] = np_(rsd[n].grad)
+    for n in p:
+        if "running" in n:
+            bit_equal(p[n], rsd[n], f"aux bn {n}")
+            fx[f"bn/{n}"] = np_(p[n])
+    return fx
+
+
+def main():
+    _, blocks = import_reference()
+    outdir = os.path.join(ROOT, "tests", "golden")
+
+    def save(name, fx):
+        path = os.path.join(outdir, name + ".npz")
+        np.savez_compressed(path, **fx)
+        print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+    save("be_heads_c32_b2_h16", heads_fixture(blocks, 32, 2, 16, 2))
+    save("be_aux_c128_to32", aux_fixture(blocks, 128, 32, 2, 12))
+    print("oracle == reference blocks composition (bit-exact) on every BE fixture")
+
+
+if __name__ == "__main__":
+    main()

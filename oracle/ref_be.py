@@ -1,0 +1,115 @@
+"""CPU oracle for the networks_BE heads and the BE loss -- TEST INFRASTRUCTURE ONLY.
+
+Functional restatement (plain torch on CPU, parameters in a dict keyed like the reference's ``state_dict``) of
+
+  * ``FeatureNet.aux_convs``         models/networks_BE.py:18-26
+  * ``MaskNet`` / ``EdgeNet``        models/networks_BE.py:39-66
+  * the loss of train_BE.py:58-59    0.5 * BCEWithLogits + ``compute_dice_loss`` (tools/ops.py:12-19)
+  * ``initialize_model``             tools/ops.py:216-229
+
+Pinning.  ``models/networks_BE.py`` imports torchvision and ``tools/ops.py`` imports cv2; neither is installed here,
+so those two files cannot be imported.  The heads are built ONLY from ``models/blocks.py`` classes, which do import:
+oracle/gen_golden_be.py composes the reference's own ``Up`` / ``Conv2d`` modules in the order of
+models/networks_BE.py:42-57 and :20-25 and asserts bit equality with this file before writing
+tests/golden/be_*.npz -> the heads are PINNED.  ``F.binary_cross_entropy_with_logits`` is torch's own function
+(pinned by construction).  ``compute_dice_loss`` and ``initialize_model`` are restated from the source text and
+checked only against torch primitives: PARITY UNPINNED for those two functions (no fixture or test of the reference
+covers them and the file that defines them cannot be executed here).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from . import ref_cpu as O
+
+Params = Dict[str, torch.Tensor]
+
+
+def aux_channels(in_channels: int = 256, target: int = 32):
+    out = []
+    for _ in range(int(math.log2(in_channels // target))):
+        out.append((in_channels, in_channels // 2, 1))
+        out.append((in_channels // 2, in_channels // 2, 3))
+        in_channels //= 2
+    return out
+
+
+def aux_convs_forward(p: Params, x: torch.Tensor, in_channels: int = 256, target: int = 32, training: bool = True,
+                      prefix: str = "aux_convs.") -> torch.Tensor:
+    """models/networks_BE.py:18-26,36: Conv2d(c, c/2, 1, bn='batch') + Conv2d(c/2, c/2, 3, bn='batch') until ``target``."""
+    for i, (_, _, k) in enumerate(aux_channels(in_channels, target)):
+        x = O.blocks_conv2d(p, f"{prefix}{i}.", x, k, 1, "batch", "relu", training)
+    return x
+
+
+def masknet_forward(p: Params, x: torch.Tensor, training: bool = True, prefix: str = "") -> torch.Tensor:
+    """models/networks_BE.py:54-58: Up(c, c/4, coord) -> Up(c/4, c/8, coord) -> three bias-only 3x3 convs (no norm, no act)."""
+    x = O.blocks_up(p, prefix + "conv1.", x, True, training)
+    x = O.blocks_up(p, prefix + "conv2.", x, True, training)
+    for i in range(3):
+        x = O.blocks_conv2d(p, f"{prefix}predictor.{i}.", x, 3, 1, None, None, training)
+    return x
+
+
+def dice_loss(inputs: torch.Tensor, targets: torch.Tensor, smooth: float = 1.0) -> torch.Tensor:
+    """tools/ops.py:12-19 (restated; parity unpinned, see the header)."""
+    nums = inputs.size(0)
+    iflat = inputs.view(nums, -1)
+    tflat = targets.view(nums, -1)
+    intersection = iflat * tflat
+    score = (2.0 * intersection.sum(1) + smooth) / (iflat.sum(1) + tflat.sum(1) + smooth)
+    return 1 - score.sum() / nums
+
+
+def be_loss(pred_logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """train_BE.py:58-59 for one head."""
+    return 0.5 * F.binary_cross_entropy_with_logits(pred_logits, targets) + dice_loss(pred_logits.sigmoid(), targets)
+
+
+def init_rule(shape, kind: str, g: torch.Generator) -> torch.Tensor:
+    """tools/ops.py:216-229 per tensor (restated; parity unpinned): conv weight kaiming_uniform_(fan_in, relu) =
+    U(+-sqrt(6 / fan_in)); biases 0; BatchNorm 1 / 0."""
+    if kind == "conv_w":
+        fan_in = shape[1] * shape[2] * shape[3]
+        bound = math.sqrt(2.0) * math.sqrt(3.0 / fan_in)
+        return (torch.rand(shape, generator=g) * 2.0 - 1.0) * bound
+    if kind in ("bn_w", "bn_rv"):
+        return torch.ones(shape)
+    if kind == "bn_nbt":
+        return torch.zeros((), dtype=torch.long)
+    return torch.zeros(shape)
+
+
+def seeded_weights(sd, seed):
+    """Deterministic weights for a blocks-built state_dict, regenerated identically by the tests (key order)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        if not v.dtype.is_floating_point or "running" in k:
+            out[k] = v.clone()
+        elif v.dim() == 4:
+            out[k] = init_rule(tuple(v.shape), "conv_w", g)
+        elif k.endswith("conv.1.weight"):
+            out[k] = torch.rand(v.shape, generator=g) + 0.5
+        else:
+            out[k] = torch.randn(v.shape, generator=g) * 0.1
+    return out
+
+
+def heads_step(p: Params, opt, feature: torch.Tensor, bimgs: torch.Tensor, eimgs: torch.Tensor):
+    """train_BE.py:54-64 below the feature map: both heads, both losses, backward, optimiser step."""
+    for n in O.trainable_names(p):
+        p[n].grad = None
+    masks = masknet_forward(p, feature, True, "mask_net.")
+    edges = masknet_forward(p, feature, True, "edge_net.")
+    loss_edge = be_loss(edges, eimgs)
+    loss_mask = be_loss(masks, bimgs)
+    losses = loss_edge + loss_mask
+    losses.backward()
+    if opt is not None:
+        opt.step()
+    return {"masks": masks.detach(), "edges": edges.detach(), "loss_edge": loss_edge.detach(), "loss_mask": loss_mask.detach()}

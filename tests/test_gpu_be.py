@@ -1,0 +1,102 @@
+"""GPU parity tests of the networks_BE row: MaskNet / EdgeNet / aux_convs drop-ins and the fused
+0.5*BCEWithLogits + dice loss on HIP kernels, against vectors produced by the reference's own blocks classes
+(tests/golden/be_*.npz) and the oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import NORTH_STAR_RTOL, assert_close, load_golden, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def dev(x):
+    return x.to(DEV)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 64, 64), (3, 1, 40, 24), (1, 2, 16, 16), (5, 1, 128, 128)])
+def test_be_loss_matches_torch(shape):
+    from oracle import ref_be as BE
+    import vae_play_amd.networks_BE as N
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g) * 3
+    tt = (torch.rand(shape, generator=g) > 0.6).float()
+    xo = x.clone().requires_grad_(True)
+    lo = BE.be_loss(xo, tt)
+    lo.backward()
+    xd = dev(x).requires_grad_(True)
+    ld = N.be_loss(xd, dev(tt))
+    (ld * 1.7).backward()
+    assert abs(ld.item() - lo.item()) <= 2e-6 * abs(lo.item()), (ld.item(), lo.item())
+    assert_close(xd.grad, xo.grad * 1.7, 2e-5, "d be_loss / d logits")
+    l2 = N.be_loss(dev(x), dev(tt))
+    assert torch.equal(l2, ld.detach()), "two-stage fp64 reduction must be bit-reproducible"
+
+
+def test_aux_convs_against_reference_golden():
+    from oracle import ref_be as BE
+    import vae_play_amd.networks_BE as N
+    g = load_golden("be_aux_c128_to32")
+    net = N.FeatureNet(None, in_channels=int(g["meta_Cin"]), target_out_channels=int(g["meta_target"]))
+    net.load_state_dict(BE.seeded_weights(net.state_dict(), int(g["weight_seed"])))
+    net = net.to(DEV).train()
+    x = dev(t(g["x"])).requires_grad_(True)
+    y = net(x)
+    assert_close(y, t(g["y"]), NORTH_STAR_RTOL, "aux y")
+    y.backward(dev(t(g["gy"])))
+    assert_close(x.grad, t(g["dx"]), NORTH_STAR_RTOL * 5, "aux dx")
+    for n, p in net.named_parameters():
+        assert_close(p.grad, t(g[f"grad/{n}"]), NORTH_STAR_RTOL * 5, f"aux grad {n}")
+    sd = net.state_dict()
+    for k in g:
+        if k.startswith("bn/"):
+            assert_close(sd[k[3:]], t(g[k]), NORTH_STAR_RTOL, f"running stat {k[3:]}")
+
+
+def test_heads_train_steps_against_reference_golden():
+    """train_BE.py:54-64 below the feature map: MaskNet + EdgeNet, both losses, backward, Adam, two steps."""
+    from oracle import ref_be as BE
+    import vae_play_amd.networks_BE as N
+    from vae_play_amd import optim
+    g = load_golden("be_heads_c32_b2_h16")
+    C, steps = int(g["meta_C"]), int(g["meta_steps"])
+    holder = torch.nn.Module()
+    holder.mask_net, holder.edge_net = N.MaskNet(C), N.EdgeNet(C)
+    holder.load_state_dict(BE.seeded_weights(holder.state_dict(), int(g["weight_seed"])))
+    holder = holder.to(DEV).train()
+    opt = optim.Adam(holder.parameters(), lr=1e-4)
+    feature, bimgs, eimgs = (dev(t(g[k])) for k in ("feature", "bimgs", "eimgs"))
+    for step in range(1, steps + 1):
+        masks = holder.mask_net(feature)
+        edges = holder.edge_net(feature)
+        loss_edge = N.be_loss(edges, eimgs)
+        loss_mask = N.be_loss(masks, bimgs)
+        opt.zero_grad()
+        (loss_edge + loss_mask).backward()
+        if step == 1:
+            assert_close(masks, t(g["masks"]), NORTH_STAR_RTOL, "masks")
+            assert_close(edges, t(g["edges"]), NORTH_STAR_RTOL, "edges")
+            for n, p in holder.named_parameters():
+                assert_close(p.grad, t(g[f"grad/{n}"]), NORTH_STAR_RTOL * 5, f"grad {n}")
+            sd = holder.state_dict()
+            for k in g:
+                if k.startswith("bn/"):
+                    assert_close(sd[k[3:]], t(g[k]), NORTH_STAR_RTOL, f"running stat {k[3:]}")
+        for k, v in (("loss_edge", loss_edge), ("loss_mask", loss_mask)):
+            ref = g[f"{k}{step}"][0]
+            assert abs(v.item() - ref) <= NORTH_STAR_RTOL * abs(ref), f"{k} step {step}: {v.item()} vs {ref}"
+        opt.step()
+        for n, p in holder.named_parameters():
+            ref = t(g[f"param{step}/{n}"])
+            d = (p.detach().cpu() - ref).abs()
+            # Adam moves a weight by ~lr per step; sign flips of ~0 gradients allowed on a small fraction of elements
+            assert d.max().item() <= 2.05e-4 * step, f"param {n} moved more than 2*lr*step"
+            assert (d > 0.05 * 1e-4 * step + 1e-7).float().mean().item() <= 0.05, f"param {n} after step {step}"
+
+
+def test_compose_net_forward_shapes():
+    import vae_play_amd.networks_BE as N
+    net = N.initialize_model(N.ComposeNet(N.FeatureNet(None, in_channels=64, target_out_channels=32))).to(DEV).train()
+    out = net(torch.randn(2, 64, 16, 16, device=DEV))
+    assert tuple(out["masks"].shape) == (2, 1, 64, 64) and tuple(out["edges"].shape) == (2, 1, 64, 64)

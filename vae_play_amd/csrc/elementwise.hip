@@ -168,6 +168,76 @@ __global__ void half_sqdiff_bwd_kernel(const float* __restrict__ a, const float*
   }
 }
 
+// ---- segmentation loss of train_BE.py:58-59: w * BCEWithLogits(x, t) (mean) + dice(sigmoid(x), t) (tools/ops.py:12-19)
+// sums[b] = { sum bce_i, sum p_i t_i, sum p_i, sum t_i } over the n elements of sample b, p = sigmoid(x).
+// Two stages (chunk partials in fp32 lanes -> fp64 tree, then a fixed-order fp64 sum over chunks): bit-reproducible.
+constexpr int BE_CHUNK = 4096;
+
+__global__ void __launch_bounds__(256) be_loss_partial_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                              double* __restrict__ part, int n, int nchunk) {
+  __shared__ double sh[4][4];
+  const int b = blockIdx.y, c = blockIdx.x;
+  const size_t base = (size_t)b * n;
+  const int i0 = c * BE_CHUNK, i1 = min(n, i0 + BE_CHUNK);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float xv = x[base + i], tv = t[base + i];
+    const float e = __expf(-fabsf(xv));
+    const float p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    s[0] += fmaxf(xv, 0.f) - xv * tv + log1pf(e);
+    s[1] += p * tv;
+    s[2] += p;
+    s[3] += tv;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double w = wave_sum_d((double)s[k]);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    part[((size_t)b * nchunk + c) * 4 + k] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+  }
+}
+
+__global__ void be_loss_final_kernel(const double* __restrict__ part, float* __restrict__ sums, float* __restrict__ loss, int B,
+                                     int n, int nchunk, float bce_weight, float smooth) {
+  __shared__ double acc[2];
+  if (threadIdx.x == 0) { acc[0] = 0.0; acc[1] = 0.0; }
+  __syncthreads();
+  if (threadIdx.x == 0) {                      // B is a minibatch size: a serial fixed-order sum is both cheap and exact
+    double bce = 0.0, dice = 0.0;
+    for (int b = 0; b < B; ++b) {
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int c = 0; c < nchunk; ++c)
+        for (int k = 0; k < 4; ++k) v[k] += part[((size_t)b * nchunk + c) * 4 + k];
+      for (int k = 0; k < 4; ++k) sums[b * 4 + k] = (float)v[k];
+      bce += v[0];
+      dice += (2.0 * v[1] + smooth) / (v[2] + v[3] + smooth);
+    }
+    loss[0] = (float)(bce_weight * bce / ((double)B * n) + 1.0 - dice / B);
+  }
+}
+
+// dx_i = g * [ w/(B n) (p_i - t_i) + (a_b t_i + b_b) p_i (1 - p_i) ],  D = P + T + s, a_b = -2/(B D), b_b = (2 I + s)/(B D^2)
+__global__ void be_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ sums,
+                                   const float* __restrict__ gptr, float* __restrict__ dx, int B, int n, float bce_weight,
+                                   float smooth) {
+  const int b = blockIdx.y;
+  const float g = gptr ? gptr[0] : 1.f;
+  const float I = sums[b * 4 + 1], D = sums[b * 4 + 2] + sums[b * 4 + 3] + smooth;
+  const float cb = g * bce_weight / ((float)B * (float)n);
+  const float ab = g * (-2.f / ((float)B * D)), bb = g * ((2.f * I + smooth) / ((float)B * D * D));
+  const size_t base = (size_t)b * n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float xv = x[base + i], tv = t[base + i];
+    const float e = __expf(-fabsf(xv));
+    const float p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dx[base + i] = cb * (p - tv) + (ab * tv + bb) * p * (1.f - p);
+  }
+}
+
 inline unsigned reduce_blocks(size_t n) { return grid_for(n / 4 + 1, 256, 1024); }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ gptr,
@@ -425,6 +495,32 @@ int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, 
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, (int)nb, out);
   return check_launch("vp_sum_f32(final)");
+}
+
+size_t vp_be_loss_workspace_bytes(int B, int n) {
+  const int nchunk = (n + BE_CHUNK - 1) / BE_CHUNK;
+  return (size_t)B * nchunk * 4 * sizeof(double);
+}
+
+int vp_be_loss_fwd_f32(const float* logits, const float* targets, float* loss, float* sums, int B, int n, float bce_weight,
+                       float smooth, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(logits && targets && loss && sums && ws && B > 0 && n > 0, "vp_be_loss_fwd_f32: bad arguments");
+  if (ws_bytes < vp_be_loss_workspace_bytes(B, n)) return fail(VP_ERR_WORKSPACE, "vp_be_loss_fwd_f32: workspace too small");
+  const int nchunk = (n + BE_CHUNK - 1) / BE_CHUNK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(be_loss_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, logits, targets, (double*)ws, n, nchunk);
+  int rc = check_launch("vp_be_loss_fwd_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(be_loss_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, sums, loss, B, n, nchunk, bce_weight, smooth);
+  return check_launch("vp_be_loss_fwd_f32(final)");
+}
+
+int vp_be_loss_bwd_f32(const float* logits, const float* targets, const float* sums, const float* gptr, float* dlogits, int B,
+                       int n, float bce_weight, float smooth, vp_stream stream) {
+  VP_REQUIRE(logits && targets && sums && dlogits && B > 0 && n > 0, "vp_be_loss_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(be_loss_bwd_kernel, dim3(grid_for((size_t)n, 256, 256), B), dim3(256), 0, (hipStream_t)stream, logits, targets,
+                     sums, gptr, dlogits, B, n, bce_weight, smooth);
+  return check_launch("vp_be_loss_bwd_f32");
 }
 
 int vp_half_sqdiff_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream) {

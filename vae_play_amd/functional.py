@@ -312,6 +312,23 @@ class _BCESum(Function):
         return ops.bce_bwd(p, t, g.reshape(1).contiguous(), 1.0), None
 
 
+class _BELoss(Function):
+    """bce_weight * BCEWithLogits(x, t) (mean) + dice(sigmoid(x), t) as one reduction + one elementwise backward."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, bce_weight: float, smooth: float):
+        logits, targets = logits.contiguous(), targets.contiguous()
+        loss, sums = ops.be_loss_fwd(logits, targets, bce_weight, smooth)
+        ctx.w, ctx.smooth = bce_weight, smooth
+        ctx.save_for_backward(logits, targets, sums)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets, sums = ctx.saved_tensors
+        return ops.be_loss_bwd(logits, targets, sums, g.reshape(1).contiguous(), ctx.w, ctx.smooth), None, None, None
+
+
 class _HalfSqDiff(Function):
     """0.5*(a-b)^2 per element ("nle", models/networks.py:267) or summed over all but the first dim (":273")."""
 
@@ -398,6 +415,12 @@ def binary_cross_entropy(p, t, reduction: str = "sum"):
     if reduction == "mean":
         return s / p.numel()
     raise ValueError("reduction must be 'sum' or 'mean'")
+
+
+def be_loss(logits, targets, bce_weight: float = 0.5, smooth: float = 1.0):
+    """train_BE.py:58-59: ``bce_weight * F.binary_cross_entropy_with_logits(logits, targets)
+    + compute_dice_loss(logits.sigmoid(), targets)`` (tools/ops.py:12-19) for (B, ...) logits; scalar."""
+    return _BELoss.apply(logits, targets, bce_weight, smooth)
 
 
 def half_sq_diff(a, b):

@@ -269,6 +269,23 @@ def bce_sigmoid_bwd(p, t, gscale: float):
     return dl
 
 
+def be_loss_fwd(logits, targets, bce_weight: float, smooth: float):
+    B, n = logits.shape[0], logits.numel() // logits.shape[0]
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    sums = torch.empty((B, 4), dtype=torch.float32, device=logits.device)
+    ws = _ws(_lib.load().vp_be_loss_workspace_bytes(B, n), logits)
+    _lib.call("vp_be_loss_fwd_f32", _p(logits), _p(targets), _p(loss), _p(sums), B, n, bce_weight, smooth, _p(ws), ws.numel() * 4,
+              _stream())
+    return loss, sums
+
+
+def be_loss_bwd(logits, targets, sums, g, bce_weight: float, smooth: float):
+    B, n = logits.shape[0], logits.numel() // logits.shape[0]
+    dx = torch.empty_like(logits)
+    _lib.call("vp_be_loss_bwd_f32", _p(logits), _p(targets), _p(sums), _p(g), _p(dx), B, n, bce_weight, smooth, _stream())
+    return dx
+
+
 def half_sqdiff(a, b):
     out = torch.empty_like(a)
     _lib.call("vp_half_sqdiff_f32", _p(a), _p(b), _p(out), a.numel(), _stream())
