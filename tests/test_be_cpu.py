@@ -68,4 +68,4 @@ def test_restated_dice_and_init_rules_against_torch_primitives():
         assert a.abs().max().item() <= math.sqrt(6.0 / fan_in) + 1e-7
     for m in net.modules():
         if getattr(m, "bias", None) is not None:
-            assert float(m.bias.abs().max()) == 0.0
+            assert float(m.bias.detach().abs().max()) == 0.0
