@@ -116,3 +116,31 @@ def test_fused_step_equals_autograd_modules_and_graph_replay():
     opt.flat_grad[~used] = 0
     fused.step(xd, epsd)
     assert torch.isfinite(opt.flat_param[used]).all()
+
+
+def test_autograd_modules_in_bf16x3_mode_match_golden():
+    """vae_play_amd.set_conv_precision("bf16x3"): the drop-in modules run their 5x5 convolutions on the split-bf16
+    kernels (inputs split on the fly); outputs stay inside the 1e-3 bar, gradients inside the bf16x3 budget."""
+    import vae_play_amd as V
+    from oracle import ref_cpu as O
+    from tests.util import load_golden, t, NORTH_STAR_RTOL
+    g = load_golden("step_64x64x3_z64_b4_adam")
+    C, S, z, B = (int(g[k]) for k in ("meta_C", "meta_S", "meta_z", "meta_B"))
+    L = O.iter_level_for(S)
+    vae = V.VAE(S, z, C, init_rule=False)
+    vae.load_state_dict(O.init_params(C, z, L, seed=0), strict=True)
+    vae = vae.to("cuda").train()
+    x, eps = O.synthetic_batch(B, C, S, z)
+    V.set_conv_precision("bf16x3")
+    try:
+        xt, mu, lv = vae(x.cuda(), eps=eps.cuda())
+        loss, recon, kl = V.vae_loss(x.cuda(), xt, mu, lv)
+        loss.backward()
+    finally:
+        V.set_conv_precision("f32")
+    assert (mu.detach().cpu() - t(g["mu"])).abs().max().item() <= NORTH_STAR_RTOL * t(g["mu"]).abs().max().item()
+    assert abs(loss.item() - g["loss"][0]) <= NORTH_STAR_RTOL * abs(g["loss"][0])
+    for n, p in vae.named_parameters():
+        l2 = g[f"grad_l2/{n}"][0]
+        got = p.grad.double().pow(2).sum().sqrt().item()
+        assert abs(got - l2) <= 5e-3 * l2 + 1e-12, f"{n}: {got} vs {l2}"

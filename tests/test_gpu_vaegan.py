@@ -42,9 +42,18 @@ def _grad_check(name, grad, g, prefix, tol=NORTH_STAR_RTOL, term_scale=0.0):
     return rel
 
 
-def test_discriminator_against_reference_golden():
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_precision(request):
+    import vae_play_amd as V
+    V.set_conv_precision(request.param)
+    yield request.param
+    V.set_conv_precision("f32")
+
+
+def test_discriminator_against_reference_golden(conv_precision):
     """models/networks.py:151-198 with 3 input channels and the tap below the top (recon_level=1): both modes,
-    output, the three input gradients, every parameter gradient, BN running statistics."""
+    output, the three input gradients, every parameter gradient, BN running statistics; with the exact-fp32 and
+    with the split-bf16 convolutions (same 1e-3 bar on the outputs)."""
     import vae_play_amd as V
     from oracle import ref_vaegan as G
     g = load_golden("vaegan_disc_c3_l2")

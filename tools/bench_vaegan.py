@@ -47,11 +47,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3")
     ap.add_argument("--five-pass", action="store_true", help="the reference's five backward(retain_graph=True) calls instead of one")
     a = ap.parse_args()
     import vae_play_amd as V
     from vae_play_amd import optim
     dev = "cuda"
+    V.set_conv_precision(a.precision)
     torch.manual_seed(0)
     net = V.VaeGan(a.img, a.z).to(dev).train()
     opts = [optim.RMSprop(m.parameters(), lr=1e-4) for m in (net.encoder, net.decoder, net.discriminator, net.param_encoder)]
@@ -70,7 +72,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     out = {"metric": "images/sec (VAE-GAN train step, train.py:43-78)", "value": round(a.batch / dt, 1), "unit": "images/sec",
            "ms_per_step": round(dt * 1e3, 3), "config": {"workload": f"VaeGan {a.img}x{a.img}x1 z={a.z} batch {a.batch}",
-                                                         "path": "autograd modules on HIP kernels (fp32 MFMA)",
+                                                         "path": f"autograd modules on HIP kernels ({a.precision} convolutions)",
                                                          "backward": "five passes (train.py:69-73)" if a.five_pass else "one pass over the summed losses"},
            "loss_encoder": float(loss)}
     if a.cpu_steps > 0:

@@ -26,14 +26,43 @@ def _cl(t: torch.Tensor) -> torch.Tensor:
     return ops.channels_last(t)
 
 
+_PRECISION = "f32"
+
+
+def set_conv_precision(mode: str) -> None:
+    """Arithmetic of the 5x5 convolutions on the autograd front end: "f32" (exact fp32 MFMA, default) or "bf16x3"
+    (split-bf16: three bf16 MFMAs per product, ~5e-6 relative error, ~3x the matrix rate; used where both channel
+    counts are multiples of 8).  The fused engine has its own ``precision=`` argument."""
+    global _PRECISION
+    if mode not in ("f32", "bf16x3"):
+        raise ValueError("precision must be 'f32' or 'bf16x3'")
+    _PRECISION = mode
+
+
+def get_conv_precision() -> str:
+    return _PRECISION
+
+
+def _use16(weight) -> bool:
+    return _PRECISION == "bf16x3" and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
+
+
 class _Conv5(Function):
     """small = act(bias + conv5x5(big)); weight (Csmall, Cbig, 5, 5) = nn.Conv2d layout."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride: int, act: int):
         x = _cl(x)
-        p0, _ = ops.pack_w5(weight, True, False)
-        y = ops.conv5_gather(x, p0, bias, stride, act)
+        ctx.x16 = _use16(weight) and act in (ACT_NONE, ACT_SIGMOID)
+        if ctx.x16:
+            xs = ops.split_f32(x)
+            p0, _ = ops.pack_w5_split(weight, True, False)
+            y = ops.conv5_gather_bf16x3(xs, x.shape, p0, weight.shape[0], bias, stride, act)
+            ctx.xshape = tuple(x.shape)
+            x = xs          # the split copy is what the weight gradient reads
+        else:
+            p0, _ = ops.pack_w5(weight, True, False)
+            y = ops.conv5_gather(x, p0, bias, stride, act)
         ctx.stride, ctx.act, ctx.has_bias = stride, act, bias is not None
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         return y
@@ -45,11 +74,19 @@ class _Conv5(Function):
         if ctx.act != ACT_NONE:
             dy = ops.act_bwd_from_y(y, dy, ctx.act)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            _, p1 = ops.pack_w5(weight, False, True)
-            dx = ops.conv5_scatter(dy, p1, ctx.stride)
-        if ctx.needs_input_grad[1]:
-            dw = ops.conv5_wgrad(x, dy, ctx.stride)
+        if ctx.x16:
+            dys = ops.split_f32(dy)
+            if ctx.needs_input_grad[0]:
+                _, p1 = ops.pack_w5_split(weight, False, True)
+                dx = ops.conv5_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.stride)
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv5_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.stride)
+        else:
+            if ctx.needs_input_grad[0]:
+                _, p1 = ops.pack_w5(weight, False, True)
+                dx = ops.conv5_scatter(dy, p1, ctx.stride)
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv5_wgrad(x, dy, ctx.stride)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             B, C, H, W = dy.shape
             db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C))
@@ -63,8 +100,16 @@ class _ConvT5(Function):
     @staticmethod
     def forward(ctx, x, weight, stride: int):
         x = _cl(x)
-        _, p1 = ops.pack_w5(weight, False, True)
-        y = ops.conv5_scatter(x, p1, stride)
+        ctx.x16 = _use16(weight)
+        if ctx.x16:
+            xs = ops.split_f32(x)
+            _, p1 = ops.pack_w5_split(weight, False, True)
+            y = ops.conv5_scatter_bf16x3(xs, x.shape, p1, weight.shape[1], stride)
+            ctx.xshape = tuple(x.shape)
+            x = xs
+        else:
+            _, p1 = ops.pack_w5(weight, False, True)
+            y = ops.conv5_scatter(x, p1, stride)
         ctx.stride = stride
         ctx.save_for_backward(x, weight)
         return y
@@ -74,6 +119,14 @@ class _ConvT5(Function):
         x, weight = ctx.saved_tensors
         dy = _cl(dy)
         dx = dw = None
+        if ctx.x16:
+            dys = ops.split_f32(dy)
+            if ctx.needs_input_grad[0]:
+                p0, _ = ops.pack_w5_split(weight, True, False)
+                dx = ops.conv5_gather_bf16x3(dys, dy.shape, p0, weight.shape[0], None, ctx.stride, ACT_NONE)
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv5_wgrad_bf16x3(dys, tuple(dy.shape), x, ctx.xshape, ctx.stride)
+            return dx, dw, None
         if ctx.needs_input_grad[0]:
             p0, _ = ops.pack_w5(weight, True, False)
             dx = ops.conv5_gather(dy, p0, None, ctx.stride, ACT_NONE)
