@@ -78,6 +78,22 @@ class _FlatOptimizer:
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.arena.zero_grad()
 
+    # ---- checkpointing: plain tensors / numbers only (vae_play_amd/checkpoint.py) -------------------------
+    _STATE = ()
+
+    def state_dict(self) -> dict:
+        out = {"kind": type(self).__name__, "lr": float(self.lr), "step_count": int(self.step_count), "numel": int(self.arena.numel)}
+        for k in self._STATE:
+            out[k] = getattr(self, k).detach().cpu()
+        return out
+
+    def load_state_dict(self, sd: dict) -> None:
+        if sd.get("kind") != type(self).__name__ or int(sd.get("numel", -1)) != self.arena.numel:
+            raise ValueError("optimizer state does not match this optimizer (kind / parameter arena size)")
+        self.lr, self.step_count = float(sd["lr"]), int(sd["step_count"])
+        for k in self._STATE:
+            getattr(self, k).copy_(sd[k])
+
     @property
     def flat_grad(self) -> torch.Tensor:
         return self.arena.flat_grad
@@ -95,6 +111,7 @@ class Adam(_FlatOptimizer):
         self.betas, self.eps = betas, eps
         self.exp_avg = torch.zeros_like(self.arena.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat_param)
+        self._STATE = ("exp_avg", "exp_avg_sq")
 
     @torch.no_grad()
     def step(self) -> None:
@@ -112,6 +129,7 @@ class RMSprop(_FlatOptimizer):
         super().__init__(params, lr)
         self.alpha, self.eps = alpha, eps
         self.square_avg = torch.zeros_like(self.arena.flat_param)
+        self._STATE = ("square_avg",)
 
     @torch.no_grad()
     def step(self) -> None:
