@@ -184,6 +184,17 @@ int vp_bce_sum_f32(const float* p, const float* t, size_t n, float* out, void* w
 int vp_bce_bwd_f32(const float* p, const float* t, const float* gptr, float gscale, float* dp, size_t n, vp_stream stream);
 /* fused sigmoid+BCE backward on the logits: dlogit = gscale * (p - t) */
 int vp_bce_sigmoid_bwd_f32(const float* p, const float* t, float gscale, float* dlogit, size_t n, vp_stream stream);
+/* ---- font network pieces (models/networks_BE_font.py, models/blocks.py:66-96, train_BE_font.py:158) ------------- */
+/* nn.AdaptiveAvgPool2d((1,1)) on NHWC: out[b][c] = mean_p x[b][p][c]; bwd: dx[b][p][c] = dy[b][c] / HW */
+int vp_global_avgpool_fwd_f32(const float* x_nhwc, float* out, int B, int HW, int C, vp_stream stream);
+int vp_global_avgpool_bwd_f32(const float* dy, float* dx_nhwc, int B, int HW, int C, vp_stream stream);
+/* nn.Softmax(dim=-1) over R rows of n; bwd: dx = y * (dy - sum_j dy_j y_j) */
+int vp_softmax_rows_fwd_f32(const float* x, float* y, int R, int n, vp_stream stream);
+int vp_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, int R, int n, vp_stream stream);
+/* F.l1_loss(a, b) (mean): out[0]; ws >= 2 * vp_reduce_workspace_bytes(n).  bwd: da = g * sign(a-b) / n, db = -da */
+int vp_l1_mean_f32(const float* a, const float* b, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_l1_mean_bwd_f32(const float* a, const float* b, const float* gptr, float* da, float* db, size_t n, vp_stream stream);
+
 /* ---- segmentation loss of train_BE.py:58-59: bce_weight * F.binary_cross_entropy_with_logits(x, t) (mean over B*n)
  * + compute_dice_loss(sigmoid(x), t, smooth) (tools/ops.py:12-19) for B samples of n logits each.
  * fwd: loss[0] and sums[B][4] = {sum bce, sum p*t, sum p, sum t} per sample (kept for the backward);

@@ -1,0 +1,95 @@
+"""Throughput of one font-GAN training iteration (train_BE_font.py:97-170): discriminator phase,
+generator phase, style-encoder phase on the drop-in ComposeNet / Discriminator with three flat-arena Adam optimisers.
+usage: python tools/bench_font.py [--img 64] [--batch 8] [--steps 5] [--cpu-steps 1]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--img", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    a = ap.parse_args()
+    import vae_play_amd.networks_BE as NB
+    import vae_play_amd.networks_BE_font as N
+    from vae_play_amd import functional as Fh
+    from vae_play_amd import optim
+    from oracle import ref_cpu as O
+    from oracle import ref_font as FN
+    dev = "cuda"
+    torch.manual_seed(0)
+    net = NB.initialize_model(N.ComposeNet(a.img))
+    disc = NB.initialize_model(N.Discriminator(a.img, 2, 143))
+    pn = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    pd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
+    net, disc = net.to(dev).train(), disc.to(dev).train()
+    opt, opt_style, opt_disc = optim.Adam(net.parameters(), lr=1e-4), optim.Adam(net.style_encoder.parameters(), lr=1e-4), \
+        optim.Adam(disc.parameters(), lr=1e-4)
+    imgs, masks, edges, labels, y = FN.synthetic_batch(a.batch, a.img)
+    dimgs, dmasks, dedges, dlabels = imgs.to(dev), masks.to(dev), edges.to(dev), labels.to(dev)
+    dy = {k: v.to(dev) for k, v in y.items()}
+    ones, zeros = torch.ones((a.batch, 1), device=dev), torch.zeros((a.batch, 1), device=dev)
+
+    def iteration():
+        with torch.no_grad():
+            pr = net(dimgs, dy)
+            pm = torch.cat([pr["masks"], pr["edges"]], dim=1)
+        d_gt_adv, d_gt_aux = disc(torch.cat([dmasks, dedges], dim=1), dy)
+        d_pr_adv, _ = disc(pm, dy)
+        opt_disc.zero_grad()
+        ((F.binary_cross_entropy(d_gt_adv, ones) + F.binary_cross_entropy(d_pr_adv, zeros)) * 0.5 + F.cross_entropy(d_gt_aux, dlabels)).backward()
+        opt_disc.step()
+        pr = net(dimgs, dy)
+        g_adv, g_aux = disc(torch.cat([pr["masks"], pr["edges"]], dim=1), dy)
+        opt.zero_grad()
+        l_gadv = F.binary_cross_entropy(g_adv, ones) * 2
+        (NB.be_loss(pr["edges"], dedges) * 10 + NB.be_loss(pr["masks"], dmasks) * 10 + l_gadv + l_gadv * 5).backward()
+        opt.step()
+        with torch.no_grad():
+            ref = net(dimgs, dy)
+        pr_ = net(dimgs)
+        opt_style.zero_grad()
+        l_embed = (Fh.l1_loss(pr_["masks"], ref["masks"]) + Fh.l1_loss(pr_["edges"], ref["edges"])) * 2.0
+        (NB.be_loss(pr_["masks"], dmasks) + NB.be_loss(pr_["edges"], dedges) + l_embed).backward()
+        opt_style.step()
+        return l_embed
+
+    for _ in range(a.warmup):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        le = iteration()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    out = {"metric": "images/sec (font GAN iteration, train_BE_font.py:97-170)", "value": round(a.batch / dt, 1), "unit": "images/sec",
+           "ms_per_step": round(dt * 1e3, 2), "config": {"workload": f"ComposeNet({a.img}) + Discriminator({a.img}, 2, 143), batch {a.batch}",
+                                                         "path": "autograd modules on HIP kernels (fp32 MFMA)"}, "loss_embed": float(le)}
+    if a.cpu_steps > 0:
+        torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+        O.require_grad(pn); O.require_grad(pd)
+        o1 = torch.optim.Adam([pn[n] for n in O.trainable_names(pn)], lr=1e-4)
+        o2 = torch.optim.Adam([pn[n] for n in FN.style_encoder_names(pn)], lr=1e-4)
+        o3 = torch.optim.Adam([pd[n] for n in O.trainable_names(pd)], lr=1e-4)
+        t0 = time.perf_counter()
+        for _ in range(a.cpu_steps):
+            FN.train_iteration(pn, pd, o1, o3, o2, imgs, masks, edges, labels, y, a.img)
+        ct = (time.perf_counter() - t0) / a.cpu_steps
+        out["cpu_baseline"] = {"value": round(a.batch / ct, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{a.cpu_steps} iteration(s), no warm-up"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -71,6 +71,12 @@ SIGNATURES = {
     "vp_bce_bwd_f32": (c_int, [P, P, P, c_float, P, c_size_t, P]),
     "vp_bce_sigmoid_bwd_f32": (c_int, [P, P, c_float, P, c_size_t, P]),
     "vp_sum_f32": (c_int, [P, c_size_t, P, P, c_size_t, P]),
+    "vp_global_avgpool_fwd_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "vp_global_avgpool_bwd_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "vp_softmax_rows_fwd_f32": (c_int, [P, P, c_int, c_int, P]),
+    "vp_softmax_rows_bwd_f32": (c_int, [P, P, P, c_int, c_int, P]),
+    "vp_l1_mean_f32": (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
+    "vp_l1_mean_bwd_f32": (c_int, [P, P, P, P, P, c_size_t, P]),
     "vp_be_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vp_be_loss_fwd_f32": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, P, c_size_t, P]),
     "vp_be_loss_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, P]),

@@ -8,8 +8,9 @@ Same constructor signatures and ``state_dict`` keys as the reference:
   Down(in, out, k, if_add_coord=False)                                                                 models/blocks.py:114-127
   Up(in, out, if_add_coord=False): 2 x [conv3 + BN + ReLU] then bilinear x2                            models/blocks.py:129-146
 Convolution, normalisation + activation, bilinear resize and coordinate channels all run as HIP kernels (k x k
-implicit GEMM on the f32 MFMA path, fused norm/activation epilogues); SCSEBlock / SelfAttentionBlock are out of
-scope.
+implicit GEMM on the f32 MFMA path, fused norm/activation epilogues).
+  SelfAttentionBlock(in_channel): q/k/v 1x1 Conv2d (+ReLU), softmax(Q K^T), gamma                     models/blocks.py:66-96
+SCSEBlock is out of scope.
 """
 from __future__ import annotations
 
@@ -143,3 +144,26 @@ class Up(nn.Module):
             x = self.add_coord(x)
         x = self.conv(x)
         return F_hip.upsample2x_bilinear(x)
+
+
+class SelfAttentionBlock(nn.Module):
+    """models/blocks.py:66-96: keys q.conv.0.*, k.conv.0.*, v.conv.0.*, gamma.  (The reference builds q/k/v with its
+    ``Conv2d`` block's default activation, so they end in a ReLU; reproduced.)"""
+
+    def __init__(self, in_channel):
+        super().__init__()
+        self.q = Conv2d(in_channel, in_channel // 8, 1)
+        self.k = Conv2d(in_channel, in_channel // 8, 1)
+        self.v = Conv2d(in_channel, in_channel, 1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return F_hip.self_attention(x, self.q(x), self.k(x), self.v(x), self.gamma)
+
+
+class GlobalAvgPool(nn.Module):
+    """nn.AdaptiveAvgPool2d((1, 1)); output (B, C, 1, 1) like the reference (no parameters)."""
+
+    def forward(self, x):
+        y = F_hip.global_avg_pool(x)
+        return y.reshape(y.size(0), y.size(1), 1, 1)

@@ -238,6 +238,86 @@ __global__ void be_loss_bwd_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+// ---- nn.AdaptiveAvgPool2d((1,1)) on NHWC (models/networks_BE_font.py:61): out[b][c] = mean over the HW pixels ------
+// one workgroup per (image, 64-channel group): 4 pixel-lanes x 64 channels, fixed-order tree -> bit-reproducible
+__global__ void __launch_bounds__(256) global_avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C) {
+  __shared__ float sh[4][64];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int p = g; p < HW; p += 4) s += x[((size_t)b * HW + p) * C + c];
+  sh[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < C) out[(size_t)b * C + c] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x])) / (float)HW;
+}
+
+__global__ void global_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t total, int HW, int C) {
+  const float inv = 1.f / (float)HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / ((size_t)HW * C);
+    dx[i] = dy[b * C + (i % C)] * inv;
+  }
+}
+
+// ---- nn.Softmax(dim=-1) over rows of n (SelfAttentionBlock, models/blocks.py:75,90): one wavefront per row --------
+__global__ void __launch_bounds__(256) softmax_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* xr = x + (size_t)row * n;
+  float m = -3.4e38f;
+  for (int j = lane; j < n; j += 64) m = fmaxf(m, xr[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  float s = 0.f;
+  for (int j = lane; j < n; j += 64) s += __expf(xr[j] - m);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int j = lane; j < n; j += 64) y[(size_t)row * n + j] = __expf(xr[j] - m) * inv;
+}
+
+// dx = y * (dy - sum_j dy_j y_j)
+__global__ void __launch_bounds__(256) softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, int R, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const size_t base = (size_t)row * n;
+  float d = 0.f;
+  for (int j = lane; j < n; j += 64) d += dy[base + j] * y[base + j];
+  d = wave_sum(d);
+  for (int j = lane; j < n; j += 64) dx[base + j] = y[base + j] * (dy[base + j] - d);
+}
+
+// ---- F.l1_loss(a, b) (mean) of train_BE_font.py:158: |a - b| partial sums, then sign(a - b) * g / n ----------------
+__global__ void __launch_bounds__(256) l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         double* __restrict__ part, size_t n) {
+  __shared__ double sh[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += fabsf(a[i] - b[i]);
+  const double w = wave_sum_d((double)s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ void l1_final_kernel(const double* __restrict__ part, int nb, size_t n, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += part[i];
+    out[0] = (float)(s / (double)n);
+  }
+}
+
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gptr,
+                              float* __restrict__ da, float* __restrict__ db, size_t n) {
+  const float g = (gptr ? gptr[0] : 1.f) / (float)n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    const float v = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    if (da) da[i] = v;
+    if (db) db[i] = -v;
+  }
+}
+
 inline unsigned reduce_blocks(size_t n) { return grid_for(n / 4 + 1, 256, 1024); }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ gptr,
@@ -495,6 +575,49 @@ int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, 
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, (int)nb, out);
   return check_launch("vp_sum_f32(final)");
+}
+
+int vp_global_avgpool_fwd_f32(const float* x_nhwc, float* out, int B, int HW, int C, vp_stream stream) {
+  VP_REQUIRE(x_nhwc && out && B > 0 && HW > 0 && C > 0, "vp_global_avgpool_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(global_avgpool_fwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x_nhwc, out, HW, C);
+  return check_launch("vp_global_avgpool_fwd_f32");
+}
+
+int vp_global_avgpool_bwd_f32(const float* dy, float* dx_nhwc, int B, int HW, int C, vp_stream stream) {
+  VP_REQUIRE(dy && dx_nhwc && B > 0 && HW > 0 && C > 0, "vp_global_avgpool_bwd_f32: bad arguments");
+  const size_t total = (size_t)B * HW * C;
+  hipLaunchKernelGGL(global_avgpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx_nhwc, total, HW, C);
+  return check_launch("vp_global_avgpool_bwd_f32");
+}
+
+int vp_softmax_rows_fwd_f32(const float* x, float* y, int R, int n, vp_stream stream) {
+  VP_REQUIRE(x && y && R > 0 && n > 0, "vp_softmax_rows_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, R, n);
+  return check_launch("vp_softmax_rows_fwd_f32");
+}
+
+int vp_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, int R, int n, vp_stream stream) {
+  VP_REQUIRE(y && dy && dx && R > 0 && n > 0, "vp_softmax_rows_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, dy, dx, R, n);
+  return check_launch("vp_softmax_rows_bwd_f32");
+}
+
+int vp_l1_mean_f32(const float* a, const float* b, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(a && b && out && ws && n > 0, "vp_l1_mean_f32: bad arguments");
+  const unsigned nb = reduce_blocks(n);
+  if (ws_bytes < nb * sizeof(double)) return fail(VP_ERR_WORKSPACE, "vp_l1_mean_f32: workspace too small (use 2 * vp_reduce_workspace_bytes)");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, s, a, b, (double*)ws, n);
+  int rc = check_launch("vp_l1_mean_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)nb, n, out);
+  return check_launch("vp_l1_mean_f32(final)");
+}
+
+int vp_l1_mean_bwd_f32(const float* a, const float* b, const float* gptr, float* da, float* db, size_t n, vp_stream stream) {
+  VP_REQUIRE(a && b && (da || db) && n > 0, "vp_l1_mean_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, gptr, da, db, n);
+  return check_launch("vp_l1_mean_bwd_f32");
 }
 
 size_t vp_be_loss_workspace_bytes(int B, int n) {

@@ -365,6 +365,82 @@ class _BCESum(Function):
         return ops.bce_bwd(p, t, g.reshape(1).contiguous(), 1.0), None
 
 
+class _GlobalAvgPool(Function):
+    """nn.AdaptiveAvgPool2d((1, 1)) + flatten: (B, C, H, W) -> (B, C)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        ctx.shape = tuple(x.shape)
+        return ops.global_avgpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.global_avgpool_bwd(dy.contiguous(), ctx.shape)
+
+
+class _SelfAttention(Function):
+    """out = gamma * (V^T att^T) + x with att = softmax(Q K^T) per image (models/blocks.py:77-96); q, k, v are the
+    already-projected (B, c', H, W) maps.  Per image: three HIP GEMMs + a row softmax; N = H*W = 1 (the only use in
+    the font model, models/networks_BE_font.py:29-45) short-circuits to out = gamma * v + x."""
+
+    @staticmethod
+    def forward(ctx, x, q, k, v, gamma):
+        x, q, k, v = _cl(x), _cl(q), _cl(k), _cl(v)
+        B, C, H, W = x.shape
+        N, C8 = H * W, q.shape[1]
+        ctx.dims = (B, C, H, W, C8)
+        if N == 1:
+            att, o = None, v
+        else:
+            qm, km, vm = (t.permute(0, 2, 3, 1).reshape(B, N, -1) for t in (q, k, v))     # views of the NHWC memory
+            att = torch.empty((B, N, N), dtype=torch.float32, device=x.device)
+            o_m = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+            for b in range(B):
+                e = ops.gemm(qm[b], C8, 1, km[b], C8, 1, N, N, C8, 0)                    # energy = Q K^T
+                att[b] = ops.softmax_rows_fwd(e)
+                ops.gemm(att[b], N, 1, vm[b], 1, C, N, C, N, 1, out=o_m[b])              # out = att V
+            o = o_m.view(B, H, W, C).permute(0, 3, 1, 2)
+        ctx.save_for_backward(q, k, v, att, o, gamma)
+        return gamma * o + x
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, att, o, gamma = ctx.saved_tensors
+        B, C, H, W, C8 = ctx.dims
+        N = H * W
+        g = _cl(g)
+        dgamma = (g * o).sum().reshape(1)
+        do = gamma * g
+        if N == 1:
+            return g, torch.zeros_like(q), torch.zeros_like(k), do, dgamma
+        qm, km, vm = (t.permute(0, 2, 3, 1).reshape(B, N, -1) for t in (q, k, v))
+        dom = _cl(do).permute(0, 2, 3, 1).reshape(B, N, C)
+        dq, dk, dv = (torch.empty((B, N, n), dtype=torch.float32, device=g.device) for n in (C8, C8, C))
+        for b in range(B):
+            ops.gemm(att[b], 1, N, dom[b], 1, C, N, C, N, 2, out=dv[b])                  # dV = att^T dO
+            datt = ops.gemm(dom[b], C, 1, vm[b], C, 1, N, N, C, 0)                       # dAtt = dO V^T
+            de = ops.softmax_rows_bwd(att[b], datt)
+            ops.gemm(de, N, 1, km[b], 1, C8, N, C8, N, 1, out=dq[b])                     # dQ = dE K
+            ops.gemm(de, 1, N, qm[b], 1, C8, N, C8, N, 2, out=dk[b])                     # dK = dE^T Q
+        to4 = lambda t, c: t.view(B, H, W, c).permute(0, 3, 1, 2)
+        return g, to4(dq, C8), to4(dk, C8), to4(dv, C), dgamma
+
+
+class _L1Mean(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return ops.l1_mean(a, b).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da, db = ops.l1_mean_bwd(a, b, g.reshape(1).contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return da, db
+
+
 class _BELoss(Function):
     """bce_weight * BCEWithLogits(x, t) (mean) + dice(sigmoid(x), t) as one reduction + one elementwise backward."""
 
@@ -468,6 +544,20 @@ def binary_cross_entropy(p, t, reduction: str = "sum"):
     if reduction == "mean":
         return s / p.numel()
     raise ValueError("reduction must be 'sum' or 'mean'")
+
+
+def global_avg_pool(x):
+    """nn.AdaptiveAvgPool2d((1, 1)) followed by the flatten of models/networks_BE_font.py:66: (B, C, H, W) -> (B, C)."""
+    return _GlobalAvgPool.apply(x)
+
+
+def self_attention(x, q, k, v, gamma):
+    return _SelfAttention.apply(x, q, k, v, gamma)
+
+
+def l1_loss(a, b):
+    """F.l1_loss(a, b) (mean)."""
+    return _L1Mean.apply(a, b)
 
 
 def be_loss(logits, targets, bce_weight: float = 0.5, smooth: float = 1.0):

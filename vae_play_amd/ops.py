@@ -269,6 +269,50 @@ def bce_sigmoid_bwd(p, t, gscale: float):
     return dl
 
 
+def global_avgpool_fwd(x):
+    """x: (B, C, H, W) channels_last -> (B, C) means."""
+    B, C, H, W = x.shape
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    _lib.call("vp_global_avgpool_fwd_f32", _p(x), _p(out), B, H * W, C, _stream())
+    return out
+
+
+def global_avgpool_bwd(dy, shape):
+    B, C, H, W = shape
+    dx = empty_cl(B, C, H, W, dy)
+    _lib.call("vp_global_avgpool_bwd_f32", _p(dy), _p(dx), B, H * W, C, _stream())
+    return dx
+
+
+def softmax_rows_fwd(x2d):
+    R, n = x2d.shape
+    y = torch.empty_like(x2d)
+    _lib.call("vp_softmax_rows_fwd_f32", _p(x2d), _p(y), R, n, _stream())
+    return y
+
+
+def softmax_rows_bwd(y2d, dy2d):
+    R, n = y2d.shape
+    dx = torch.empty_like(y2d)
+    _lib.call("vp_softmax_rows_bwd_f32", _p(y2d), _p(dy2d), _p(dx), R, n, _stream())
+    return dx
+
+
+def l1_mean(a, b):
+    n = a.numel()
+    ws = _ws(2 * _lib.load().vp_reduce_workspace_bytes(n), a)
+    out = torch.empty((1,), dtype=torch.float32, device=a.device)
+    _lib.call("vp_l1_mean_f32", _p(a), _p(b), n, _p(out), _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+def l1_mean_bwd(a, b, g, want_a: bool, want_b: bool):
+    da = torch.empty_like(a) if want_a else None
+    db = torch.empty_like(a) if want_b else None
+    _lib.call("vp_l1_mean_bwd_f32", _p(a), _p(b), _p(g), _p(da), _p(db), a.numel(), _stream())
+    return da, db
+
+
 def be_loss_fwd(logits, targets, bce_weight: float, smooth: float):
     B, n = logits.shape[0], logits.numel() // logits.shape[0]
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)

@@ -25,10 +25,15 @@ class FlatArena:
     """Owns flat parameter / gradient buffers and re-points the nn.Parameters at views of them."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        if not self.params:
+        allp: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not allp:
             raise ValueError("optimizer got an empty parameter list")
-        dev = self.params[0].device
+        # parameters that already live in another optimiser's arena (train_BE_font.py:280-281 builds one Adam over
+        # net.parameters() and a second one over net.style_encoder.parameters()) stay where they are: this optimiser
+        # keeps private state for them and updates them one tensor at a time
+        self.foreign: List[torch.nn.Parameter] = [p for p in allp if getattr(p, "_vp_arena", None) is not None]
+        self.params = [p for p in allp if getattr(p, "_vp_arena", None) is None]
+        dev = allp[0].device
         self.offsets, off = [], 0
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
@@ -36,17 +41,21 @@ class FlatArena:
             self.offsets.append(off)
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = off
-        self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_param = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.flat_param[o:o + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+                p._vp_arena = self
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
+        for p in self.foreign:
+            if p.grad is not None:
+                p.grad.zero_()
         for p, o in zip(self.params, self.offsets):  # keep .grad pointing into the arena
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
@@ -112,14 +121,23 @@ class Adam(_FlatOptimizer):
         self.exp_avg = torch.zeros_like(self.arena.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat_param)
         self._STATE = ("exp_avg", "exp_avg_sq")
+        # parameters owned by another arena: per-tensor state and step count (torch skips a tensor without a gradient)
+        self._fstate = [(p, torch.zeros_like(p.data), torch.zeros_like(p.data), [0]) for p in self.arena.foreign]
 
     @torch.no_grad()
     def step(self) -> None:
         self.step_count += 1
         a = self.arena
-        a.gather_grads()
-        ops.adam_step(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.step_count, self.grad_scale)
+        if a.numel:
+            a.gather_grads()
+            ops.adam_step(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
+                          self.eps, self.step_count, self.grad_scale)
+        for p, m, v, cnt in self._fstate:
+            if p.grad is None:
+                continue
+            cnt[0] += 1
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            ops.adam_step(p.data, g, m, v, self.lr, self.betas[0], self.betas[1], self.eps, cnt[0], self.grad_scale)
 
 
 class RMSprop(_FlatOptimizer):
@@ -130,10 +148,16 @@ class RMSprop(_FlatOptimizer):
         self.alpha, self.eps = alpha, eps
         self.square_avg = torch.zeros_like(self.arena.flat_param)
         self._STATE = ("square_avg",)
+        self._fstate = [(p, torch.zeros_like(p.data)) for p in self.arena.foreign]
 
     @torch.no_grad()
     def step(self) -> None:
         self.step_count += 1
         a = self.arena
-        a.gather_grads()
-        ops.rmsprop_step(a.flat_param, a.flat_grad, self.square_avg, self.lr, self.alpha, self.eps, self.grad_scale)
+        if a.numel:
+            a.gather_grads()
+            ops.rmsprop_step(a.flat_param, a.flat_grad, self.square_avg, self.lr, self.alpha, self.eps, self.grad_scale)
+        for p, sq in self._fstate:
+            if p.grad is not None:
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                ops.rmsprop_step(p.data, g, sq, self.lr, self.alpha, self.eps, self.grad_scale)
