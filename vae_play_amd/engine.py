@@ -45,17 +45,31 @@ class _Plan:
         a = list(args) + [None]
         self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, ""])
 
-    def run(self, stream_ptr: int, timers: Optional[dict] = None, start: int = 0, stop: Optional[int] = None):
+    def run(self, stream_ptr: int, timers: Optional[dict] = None, start: int = 0, stop: Optional[int] = None, side=None):
         s = c_void_p(stream_ptr)
-        for name, fn, a, slot, flops, tag in self.calls[start:stop]:
-            a[slot] = s
+        for ci, (name, fn, a, slot, flops, tag) in enumerate(self.calls[start:stop], start):
+            on_side = side is not None and "wgrad" in name and name.startswith("vp_conv5")
+            if on_side:
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)
+                a[slot] = c_void_p(side.cuda_stream)
+            else:
+                a[slot] = s
             timed = timers is not None and name in timers["names"]
             if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                pool = timers.get("pool")
+                if pool is not None:      # events are created once per (instrumented-step slot, call) and re-recorded
+                    key = (id(self), ci, timers.get("slot", 0))
+                    if key not in pool:
+                        pool[key] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    e0, e1 = pool[key]
+                else:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side) if on_side else e0.record()
             rc = fn(*a)
             if timed:
-                e1.record()
+                e1.record(side) if on_side else e1.record()
                 timers["events"].append((name, tag, flops, e0, e1))
             if rc != 0:
                 _lib.check(rc, name)
@@ -389,8 +403,14 @@ class FusedVAEStep:
     # ---- execution ---------------------------------------------------------------------------
     def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None, on_dense_grads=None):
         s = torch.cuda.current_stream().cuda_stream
+        import os
+        side = None
+        if os.environ.get("VP_SIDE_WGRAD", "0") == "1":      # EXPERIMENT (timing only: operand buffers are not double-buffered)
+            if not hasattr(self, "_side"):
+                self._side = torch.cuda.Stream()
+            side = self._side
         self._fwd.run(s, timers)
-        self._bwd_dec.run(s, timers)
+        self._bwd_dec.run(s, timers, side=side)
         if on_decoder_grads is not None:
             on_decoder_grads()
         self._bwd_a.run(s, timers)
@@ -398,7 +418,9 @@ class FusedVAEStep:
         self._bwd_b.run(s, timers, 0, self._bwd_b_dense_done)
         if on_dense_grads is not None:
             on_dense_grads()
-        self._bwd_b.run(s, timers, self._bwd_b_dense_done)
+        self._bwd_b.run(s, timers, self._bwd_b_dense_done, side=side)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         torch.add(self.recon, self.kl_sum, out=self._loss_num)
 
     def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None,
