@@ -16,6 +16,7 @@ with the model/loss of models/networks.py (Encoder :72-78, reparameterize :228-2
 """
 from __future__ import annotations
 
+import os
 from ctypes import c_void_p
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -30,30 +31,41 @@ _ACT_RELU, _ACT_NONE, _ACT_SIGMOID = ops.ACT_RELU, ops.ACT_NONE, ops.ACT_SIGMOID
 class _Plan:
     """A list of (c_function, argument list) with the stream slot patched at run time.
     ``flops`` is the algorithmic FLOP count of a call (0 for bandwidth-bound glue); ``timers`` lets
-    bench.py bracket selected calls with HIP events on the launch stream."""
+    bench.py bracket selected calls with HIP events on the launch stream.
+
+    A call added with ``side=k`` runs on the side stream (after everything enqueued on the main stream so far) and
+    records side event k when it is done; ``wait_side(k)`` makes the main stream wait for that event.  Used to run
+    the weight-gradient GEMMs underneath the HBM-bound BatchNorm backward kernels of the next layer."""
 
     def __init__(self):
         self.calls: List[list] = []
 
-    def add(self, name: str, *args, flops: float = 0.0, tag: str = ""):
+    def add(self, name: str, *args, flops: float = 0.0, tag: str = "", side: Optional[int] = None):
         fn = getattr(_lib.load(), name)
         a = list(args) + [None]  # last argument of every entry point is the stream
-        self.calls.append([name, fn, a, len(a) - 1, flops, tag])
+        self.calls.append([name, fn, a, len(a) - 1, flops, tag, side])
 
     def add_first(self, name: str, *args):
         fn = getattr(_lib.load(), name)
         a = list(args) + [None]
-        self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, ""])
+        self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, "", None])
+
+    def wait_side(self, k: int):
+        self.calls.append(["__wait_side__", None, [k], 0, 0.0, "", None])
 
     def run(self, stream_ptr: int, timers: Optional[dict] = None, start: int = 0, stop: Optional[int] = None, side=None):
+        """``side`` = (torch.cuda.Stream, list of torch.cuda.Event) or None (everything on the main stream)."""
         s = c_void_p(stream_ptr)
-        for ci, (name, fn, a, slot, flops, tag) in enumerate(self.calls[start:stop], start):
-            on_side = side is not None and "wgrad" in name and name.startswith("vp_conv5")
+        for ci, (name, fn, a, slot, flops, tag, sev) in enumerate(self.calls[start:stop], start):
+            if fn is None:                                   # main stream waits for a side event
+                if side is not None:
+                    torch.cuda.current_stream().wait_event(side[1][a[0]])
+                continue
+            on_side = side is not None and sev is not None
             if on_side:
-                ev = torch.cuda.Event()
-                ev.record()
-                side.wait_event(ev)
-                a[slot] = c_void_p(side.cuda_stream)
+                side[2].record()                             # fork: the side stream starts after the main stream's work so far
+                side[0].wait_event(side[2])
+                a[slot] = c_void_p(side[0].cuda_stream)
             else:
                 a[slot] = s
             timed = timers is not None and name in timers["names"]
@@ -66,11 +78,13 @@ class _Plan:
                     e0, e1 = pool[key]
                 else:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(side) if on_side else e0.record()
+                e0.record(side[0]) if on_side else e0.record()
             rc = fn(*a)
             if timed:
-                e1.record(side) if on_side else e1.record()
+                e1.record(side[0]) if on_side else e1.record()
                 timers["events"].append((name, tag, flops, e0, e1))
+            if on_side:
+                side[1][sev].record(side[0])
             if rc != 0:
                 _lib.check(rc, name)
 
@@ -132,6 +146,17 @@ class FusedVAEStep:
         fwd, bwd = _Plan(), _Plan()
         P = _ptr
         pack_jobs = []   # every conv weight is re-packed by ONE launch at the head of the forward plan
+        # Weight gradients go to a side stream (bf16x3 plans): they only feed the optimiser, so they can run underneath
+        # the next layer's HBM-bound BatchNorm backward.  The split output gradient they read is ping-ponged between
+        # two buffers; before a buffer is rewritten the main stream waits for the weight gradient that read it.
+        side_on = self.precision == "bf16x3"
+        n_side = [0]
+
+        def side_slot():
+            if not side_on:
+                return None
+            n_side[0] += 1
+            return n_side[0] - 1
 
         def pack(weight, p0, p1, Cs, Cb, split, Cs_pad=0):
             pack_jobs.append(_lib.PackJob(weight.data_ptr(), p0.data_ptr() if p0 is not None else None,
@@ -302,7 +327,7 @@ class FusedVAEStep:
         bwd.add("vp_colsum_f32", P(dlogit), P(grad_of(fin.bias)), B * S * S, C, P(ws_cs), ws_cs.numel() * 4)
         ws_wg = self._ws("g.wgrad.ws", self._max_wgrad_ws(enc_rec, dec_rec, Cf))
         bwd.add("vp_conv5_wgrad_f32", P(dec_in[-1]), P(dlogit), P(grad_of(fin.weight)), B, S, S, Cf, C, 1, P(ws_wg), ws_wg.numel() * 4,
-                flops=50.0 * B * S * S * Cf * C, tag="fin.wgrad")
+                flops=50.0 * B * S * S * Cf * C, tag="fin.wgrad", side=side_slot())   # reads dlogit / dec_in[-1]: both live on
         # two ping-pong gradient buffers sized for the largest activation
         big = max([B * F0, B * F1, n_pix] + [B * 4 * r[3] * r[3] * r[2] for r in dec_rec] + [B * r[3] * r[3] * r[2] for r in enc_rec]
                   + [B * S * S * Cf])
@@ -312,15 +337,28 @@ class FusedVAEStep:
         else:
             bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         cur, other = gA, gB
-        gS = self._sbuf("g.S", big) if x3 else None     # split gradient (output of BN backward) for the 16-bit kernels
+        # split gradient (output of BN backward) for the 16-bit kernels, two buffers used alternately
+        gS2 = [self._sbuf("g.S0", big), self._sbuf("g.S1", big)] if x3 else [None, None]
+        gs_last = [None, None]      # side event of the weight gradient that last read each buffer
+        gs_turn = [0]
+
+        def next_gs(plan):
+            k = gs_turn[0] % 2
+            gs_turn[0] += 1
+            if gs_last[k] is not None:
+                plan.wait_side(gs_last[k])
+            return k
         for i in range(L - 1, -1, -1):
             blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws = dec_rec[i]
             R = B * 4 * Hs * Hs
             fl = 50.0 * B * Hs * Hs * Cin * Cout
             if dec16[i]:
+                k = next_gs(bwd)
+                gS = gS2[k]
                 bn_block_bwd(tbuf, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)      # gS = d t_i (split)
+                gs_last[k] = side_slot()
                 bwd.add("vp_conv5_wgrad_bf16x3", P(gS), P(dec_in_s[i]), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2,
-                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"dec{i}.wgrad")
+                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"dec{i}.wgrad", side=gs_last[k])
                 bwd.add("vp_conv5_gather_bf16x3", P(gS), P(p0), None, P(cur), B, Hs, Hs, Cout, Cin, 2, _ACT_NONE,
                         flops=fl, tag=f"dec{i}.dgrad")                                     # cur = d input_i
             else:
@@ -336,11 +374,12 @@ class FusedVAEStep:
                                             lib.vp_gemm_workspace_bytes(Z, 1024, B), lib.vp_gemm_workspace_bytes(B, 1024, Z)))
         wsn = ws_g1.numel() * 4
         bwd.add("vp_gemm_f32", P(cur), 1, F1, P(self.z), 1, Z, P(grad_of(dfc_lin.weight)), Z, None, F1, Z, B, 2, P(ws_g1), wsn)
-        # every decoder gradient is final here: the data-parallel step may start reducing that slice of the arena
-        self._bwd_dec = bwd
-        bwd = _Plan()
         dz = self._buf("g.dz", B, Z)
         bwd.add("vp_gemm_f32", P(cur), F1, 1, P(dfc_lin.weight), 1, Z, P(dz), Z, None, B, Z, F1, 1, P(ws_g1), wsn)
+        # every decoder gradient is final and no decoder parameter is read any more: the data-parallel step may start
+        # reducing that slice of the arena and the optimiser may update it
+        self._bwd_dec = bwd
+        bwd = _Plan()
         dmu, dlv = self._buf("g.dmu", B, Z), self._buf("g.dlv", B, Z)
         bwd.add("vp_latent_bwd_f32", P(self.mu), P(self.logvar), P(self.eps), P(dz), None, inv_b, P(dmu), P(dlv), B, Z)
         ws_cs2 = self._ws("g.colsum2.ws", lib.vp_colsum_workspace_bytes(B, Z))
@@ -362,9 +401,10 @@ class FusedVAEStep:
 
         bn_block_bwd2(h, dhb_a, dh, B, 1024, fc_bn, h_mean, h_rstd, h_ws)
         bwd.add("vp_gemm_f32", P(dh), 1, 1024, P(flat), 1, F0, P(grad_of(fc_lin.weight)), F0, None, 1024, F0, B, 2, P(ws_g1), wsn)
-        # the encoder's dense gradients (fc.0 = 134 MB at config 3, fc.1, l_mu, l_var) are final here: second bucket
-        self._bwd_b_dense_done = len(bwd.calls)
         bwd.add("vp_gemm_f32", P(dh), 1024, 1, P(fc_lin.weight), 1, F0, P(gA), F0, None, B, F0, 1024, 1, P(ws_g1), wsn)
+        # the encoder's dense gradients (fc.0 = 134 MB at config 3, fc.1, l_mu, l_var) are final and its dense
+        # parameters are not read any more: second bucket
+        self._bwd_b_dense_done = len(bwd.calls)
         bwd.add("vp_nchw_to_nhwc_f32", P(gA), P(gB), B, size, 8, 8)
         cur, other = gB, gA
         for i in range(L - 1, -1, -1):
@@ -372,22 +412,27 @@ class FusedVAEStep:
             R = B * Hs * Hs
             fl = 50.0 * B * Hs * Hs * Cin * Cout
             if enc16[i]:
+                k = next_gs(bwd)
+                gS = gS2[k]
                 bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)        # gS = d c_i (split)
+                gs_last[k] = side_slot()
                 bwd.add("vp_conv5_wgrad_bf16x3", P(enc_in_s[i]), P(gS), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,
-                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"enc{i}.wgrad")
+                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"enc{i}.wgrad", side=gs_last[k])
                 if i > 0:
                     bwd.add("vp_conv5_scatter_bf16x3", P(gS), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
                             flops=fl, tag=f"enc{i}.dgrad")                                 # cur = d a_{i-1}
             else:
                 bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)            # other = d c_i
+                # side stream only for the last layer of the walk (i == 0): nothing rewrites `other` after it
                 bwd.add("vp_conv5_wgrad_f32", P(enc_in[i]), P(other), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,
-                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"enc{i}.wgrad")
+                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"enc{i}.wgrad", side=(side_slot() if i == 0 else None))
                 if i > 0:
                     bwd.add("vp_conv5_scatter_f32", P(other), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
                             flops=fl, tag=f"enc{i}.dgrad")                                 # cur = d a_{i-1}
         self._pack_jobs = (_lib.PackJob * len(pack_jobs))(*pack_jobs)   # host array read by every call: keep it alive
         fwd.add_first("vp_pack_w5_batch", self._pack_jobs, len(pack_jobs))
         self._fwd, self._bwd_b = fwd, bwd
+        self._n_side_events = n_side[0]
         self._bn_mods = [m for m in self.vae.modules() if hasattr(m, "num_batches_tracked")]
 
     def _max_wgrad_ws(self, enc_rec, dec_rec, Cf) -> int:
@@ -403,15 +448,12 @@ class FusedVAEStep:
     # ---- execution ---------------------------------------------------------------------------
     def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None, on_dense_grads=None):
         s = torch.cuda.current_stream().cuda_stream
-        import os
-        side = None
-        if os.environ.get("VP_SIDE_WGRAD", "0") == "1":      # EXPERIMENT (timing only: operand buffers are not double-buffered)
-            if not hasattr(self, "_side"):
-                self._side = torch.cuda.Stream()
-            side = self._side
+        side = self._side_ctx()
         self._fwd.run(s, timers)
         self._bwd_dec.run(s, timers, side=side)
         if on_decoder_grads is not None:
+            if side is not None:                         # the decoder's weight gradients are produced on the side stream
+                torch.cuda.current_stream().wait_stream(side[0])
             on_decoder_grads()
         self._bwd_a.run(s, timers)
         self._dhb[0].add_(self._dhb[1])          # d hb = dgrad(mu head) + dgrad(logvar head)  (B x 1024)
@@ -420,8 +462,16 @@ class FusedVAEStep:
             on_dense_grads()
         self._bwd_b.run(s, timers, self._bwd_b_dense_done, side=side)
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(side[0])
         torch.add(self.recon, self.kl_sum, out=self._loss_num)
+
+    def _side_ctx(self):
+        """(side stream, its events, fork event) when weight gradients run concurrently (bf16x3 plans, VP_SIDE_WGRAD != 0)."""
+        if not self._n_side_events or os.environ.get("VP_SIDE_WGRAD", "1") == "0":
+            return None
+        if not hasattr(self, "_side"):
+            self._side = (torch.cuda.Stream(), [torch.cuda.Event() for _ in range(self._n_side_events)], torch.cuda.Event())
+        return self._side
 
     def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None,
                          on_dense_grads=None):
@@ -477,7 +527,10 @@ class FusedVAEStep:
         soon as its gradients are final so that the all-reduce runs on the communicator's stream underneath the rest
         of backward: the decoder slice after the decoder's backward, the encoder's dense slice (fc.0 is 134 MB of the
         213 MB at config 3) after its weight gradient, and the encoder's conv slice (17 MB) after backward; the
-        optimiser kernel waits for all three.  ``overlap=False`` issues one all-reduce of the whole arena."""
+        optimiser kernel waits for all three.  ``overlap=False`` issues one all-reduce of the whole arena.
+        (Updating each slice right after its all-reduce, on a second side stream underneath the rest of backward, was
+        measured and is NOT done: the HBM-bound optimiser kernel slows the concurrent kernels by more than it hides,
+        4.52 vs 4.46 ms/step on one GPU; ``optim.*.step_range`` remains available.)"""
         if self.world > 1 and overlap:
             g = self.opt.flat_grad
             cut = self._decoder_slice_start()

@@ -124,6 +124,19 @@ class Adam(_FlatOptimizer):
         # parameters owned by another arena: per-tensor state and step count (torch skips a tensor without a gradient)
         self._fstate = [(p, torch.zeros_like(p.data), torch.zeros_like(p.data), [0]) for p in self.arena.foreign]
 
+    # ---- sliced update (engine.FusedVAEStep.step): begin_step() once, then step_range() per arena slice ---------
+    def begin_step(self) -> None:
+        self.step_count += 1
+
+    @torch.no_grad()
+    def step_range(self, lo: int, hi: int) -> None:
+        """Update arena elements [lo, hi) (offsets are multiples of 64 floats) with the current step count; the
+        gradients must already be in the arena (the fused engine writes them there)."""
+        if hi > lo:
+            a = self.arena
+            ops.adam_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
+                          self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale)
+
     @torch.no_grad()
     def step(self) -> None:
         self.step_count += 1
@@ -149,6 +162,16 @@ class RMSprop(_FlatOptimizer):
         self.square_avg = torch.zeros_like(self.arena.flat_param)
         self._STATE = ("square_avg",)
         self._fstate = [(p, torch.zeros_like(p.data)) for p in self.arena.foreign]
+
+    def begin_step(self) -> None:
+        self.step_count += 1
+
+    @torch.no_grad()
+    def step_range(self, lo: int, hi: int) -> None:
+        if hi > lo:
+            a = self.arena
+            ops.rmsprop_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.square_avg[lo:hi], self.lr, self.alpha, self.eps,
+                             self.grad_scale)
 
     @torch.no_grad()
     def step(self) -> None:
