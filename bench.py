@@ -153,7 +153,9 @@ def main():
     # HIP events bracket the convolution launches of TWO timed steps only (the first and the middle one), with
     # pre-created events: an event record is a barrier packet on the stream and 52 of them per step cost 0.4-2 ms of
     # pipeline bubbles, which made the figure depend on how many steps were instrumented (measured: 4.7 ms/step bare,
-    # 5.1-6.6 ms with every step or every 5th step instrumented and events created on the fly)
+    # 5.1-6.6 ms with every step or every 5th step instrumented and events created on the fly).  The two instrumented
+    # steps also run the SERIAL schedule (weight gradients on the main stream instead of the side stream) so that an
+    # event pair times one kernel alone; the other K-2 steps run the concurrent schedule.
     inst = sorted({0, args.steps // 2})[:N_INST] if timers is not None else []
     barrier()
     t0 = time.perf_counter()

@@ -448,7 +448,9 @@ class FusedVAEStep:
     # ---- execution ---------------------------------------------------------------------------
     def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None, on_dense_grads=None):
         s = torch.cuda.current_stream().cuda_stream
-        side = self._side_ctx()
+        # instrumented steps run the serial schedule: an event pair around a kernel that shares the GPU with another
+        # stream's kernels would time the mixture, not the kernel
+        side = self._side_ctx() if timers is None else None
         self._fwd.run(s, timers)
         self._bwd_dec.run(s, timers, side=side)
         if on_decoder_grads is not None:
