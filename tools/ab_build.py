@@ -1,0 +1,47 @@
+"""Like tools/ab_env.py, but for switches that are read when the fused plan is BUILT (workspace sizes, tile choices):
+builds one FusedVAEStep per value in the same process and alternates between them.
+usage: python tools/ab_build.py VAR valueA valueB [rounds] [steps]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    var, vals = sys.argv[1], sys.argv[2:4]
+    rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+    import vae_play_amd as V
+    from vae_play_amd import optim
+    from vae_play_amd.engine import FusedVAEStep
+    x, eps = torch.rand(32, 3, 128, 128, device="cuda"), torch.randn(32, 128, device="cuda")
+    sts = {}
+    for v in vals:
+        os.environ[var] = v
+        torch.manual_seed(0)
+        vae = V.VAE(128, 128, 3).cuda()
+        opt = optim.Adam(vae.parameters(), lr=1e-4)
+        sts[v] = FusedVAEStep(vae, opt, 32, 128, 3)
+        for _ in range(5):
+            sts[v].step(x, eps)
+    torch.cuda.synchronize()
+    res = {v: [] for v in vals}
+    for _ in range(rounds):
+        for v in vals:
+            os.environ[var] = v
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sts[v].step(x, eps)
+            torch.cuda.synchronize()
+            res[v].append((time.perf_counter() - t0) / steps * 1e3)
+    for v in vals:
+        r = sorted(res[v])
+        print(f"{var}={v}: median {r[len(r) // 2]:.3f} ms  min {r[0]:.3f}  max {r[-1]:.3f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -562,10 +562,12 @@ struct Tile16 { int bm, bn; };   // wave grid: 2 x 2, or 4 x 1 for the 32-column
 
 inline Tile16 choose_tile16(long M, long N, int gz, bool km = false) {
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
+  long MINB = 384;
+  if (const char* e = getenv("VP_TILE_BLOCKS")) MINB = atol(e);          // A/B knob
   // a 32-column operand (the 32-channel end of the last decoder block): 64-column tiles would idle half the MFMAs
-  if (N <= 32 && M >= 128) return (M >= 256 && blocks(256, 32) >= 384) ? Tile16{256, 32} : Tile16{128, 32};
-  if (M >= 128 && N >= 128 && blocks(128, 128) >= 384) return {128, 128};
-  if (M >= 128 && N >= 64 && blocks(128, 64) >= 384) return {128, 64};
+  if (N <= 32 && M >= 128) return (M >= 256 && blocks(256, 32) >= MINB) ? Tile16{256, 32} : Tile16{128, 32};
+  if (M >= 128 && N >= 128 && blocks(128, 128) >= MINB) return {128, 128};
+  if (M >= 128 && N >= 64 && blocks(128, 64) >= MINB) return {128, 64};
   return {64, 64};
 }
 

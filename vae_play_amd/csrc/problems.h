@@ -19,6 +19,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define VP_HD __host__ __device__ __forceinline__
@@ -452,11 +453,16 @@ inline ProbT make_probT(const float* small, const float* wp1, float* out, const 
   return p;
 }
 
-// K (= pixels) is split so that tiles * 25 taps * nsplit fills the 256 CUs a few times over.
+// K (= pixels) is split so that tiles * 25 taps * nsplit gives every CU one to two workgroups.
 inline int wgrad_nsplit(const ConvGeom& g) {
   long K = (long)g.B * g.Hs * g.Ws;
   long tiles = ((g.Cs + 127) / 128) * (long)((g.Cb + 127) / 128) * g.nt;
-  long want = (512 + tiles - 1) / tiles;
+  // ~1.5 workgroups per CU: measured optimum with the weight gradients on the side stream (tools/ab_build.py:
+  // 256 -> 4.61, 320 -> 4.56, 384 -> 4.35, 448 -> 4.37, 512 -> 4.44, 768 -> 4.47 ms/step); fewer splits also mean
+  // smaller slabs for the reduction kernel
+  long target = 384;
+  if (const char* e = getenv("VP_WGRAD_BLOCKS")) target = atol(e);      // A/B knob
+  long want = (target + tiles - 1) / tiles;
   long maxs = (K + 511) / 512;  // keep >= 16 K-tiles of 32 per split
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
@@ -484,7 +490,12 @@ inline int gemm_nsplit(long M, long N, long K) {
   long bm = M <= 32 ? 32 : 128, bn = M <= 32 ? 128 : (N <= 32 ? 32 : 128);
   long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   if (tiles >= 128) return 1;
-  long want = (512 + tiles - 1) / tiles;
+  // ~1.5 workgroups per CU: measured optimum with the weight gradients on the side stream (tools/ab_build.py:
+  // 256 -> 4.61, 320 -> 4.56, 384 -> 4.35, 448 -> 4.37, 512 -> 4.44, 768 -> 4.47 ms/step); fewer splits also mean
+  // smaller slabs for the reduction kernel
+  long target = 384;
+  if (const char* e = getenv("VP_WGRAD_BLOCKS")) target = atol(e);      // A/B knob
+  long want = (target + tiles - 1) / tiles;
   long maxs = (K + 255) / 256;
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
