@@ -2,6 +2,7 @@
 // activation once with 16-B loads; reductions are per-thread fp32 partials -> LDS tree ->
 // per-chunk slab -> fp64 finalize (deterministic, no atomics).
 //   R = B*H*W for BatchNorm2d, R = B for BatchNorm1d (models/networks.py:16,40,66,89).
+#include <stdlib.h>
 #include "common.h"
 #include "problems.h"
 #include "split.h"
@@ -17,7 +18,9 @@ struct BnGrid { int chunks_r, chunks_c, rows_per_chunk; };
 inline BnGrid bn_grid(int R, int C) {
   BnGrid g;
   g.chunks_c = (C + BN_CH - 1) / BN_CH;
-  int want = 1024 / g.chunks_c;
+  int total = 1024;
+  if (const char* e = getenv("VP_BN_BLOCKS")) total = atoi(e);          // A/B knob
+  int want = total / g.chunks_c;
   if (want < 1) want = 1;
   int maxr = (R + 63) / 64;   // at least ~64 rows per chunk
   if (maxr < 1) maxr = 1;

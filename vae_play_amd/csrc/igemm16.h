@@ -735,15 +735,16 @@ inline void launch_igemm16_dma(const P& p, long M, long N, int gz, hipStream_t s
 // register-staged BK=64 kernel on every layer (profiles/r01_c_notes.md): a 32-deep tile is 768 MFMA cycles,
 // too short to cover the DMA latency; it needs counted vmcnt + raw barriers + a third buffer to pay off.
 inline int igemm16_use_dma() {
-  static int v = [] { const char* e = getenv("VP_IGEMM16_DMA"); return e ? atoi(e) : 0; }();
-  return v;
+  const char* e = getenv("VP_IGEMM16_DMA");       // read per call: tools/ab_env.py flips it inside one process
+  return e ? atoi(e) : 0;
 }
 
 // K-tile depth: 64 for the gather/scatter families (half the barriers per MFMA), 32 for the weight
 // gradient (its [pixel][channel] LDS images at depth 64 leave one workgroup per CU).  Measured on
 // MI355X, profiles/; VP_IGEMM16_BK=32|64 overrides both for A/B runs.
 inline int igemm16_bk(bool km) {
-  static int forced = [] { const char* e = getenv("VP_IGEMM16_BK"); return e ? atoi(e) : 0; }();
+  const char* e = getenv(km ? "VP_IGEMM16_BK_W" : "VP_IGEMM16_BK");
+  const int forced = e ? atoi(e) : 0;
   if (forced == 32 || forced == 64) return forced;
   return km ? 32 : 64;
 }

@@ -490,11 +490,8 @@ inline int gemm_nsplit(long M, long N, long K) {
   long bm = M <= 32 ? 32 : 128, bn = M <= 32 ? 128 : (N <= 32 ? 32 : 128);
   long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   if (tiles >= 128) return 1;
-  // ~1.5 workgroups per CU: measured optimum with the weight gradients on the side stream (tools/ab_build.py:
-  // 256 -> 4.61, 320 -> 4.56, 384 -> 4.35, 448 -> 4.37, 512 -> 4.44, 768 -> 4.47 ms/step); fewer splits also mean
-  // smaller slabs for the reduction kernel
   long target = 384;
-  if (const char* e = getenv("VP_WGRAD_BLOCKS")) target = atol(e);      // A/B knob
+  if (const char* e = getenv("VP_GEMM_BLOCKS")) target = atol(e);       // A/B knob
   long want = (target + tiles - 1) / tiles;
   long maxs = (K + 255) / 256;
   long s = want < maxs ? want : maxs;

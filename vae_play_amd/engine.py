@@ -45,10 +45,10 @@ class _Plan:
         a = list(args) + [None]  # last argument of every entry point is the stream
         self.calls.append([name, fn, a, len(a) - 1, flops, tag, side])
 
-    def add_first(self, name: str, *args):
+    def add_first(self, name: str, *args, side: Optional[int] = None):
         fn = getattr(_lib.load(), name)
         a = list(args) + [None]
-        self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, "", None])
+        self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, "", side])
 
     def wait_side(self, k: int):
         self.calls.append(["__wait_side__", None, [k], 0, 0.0, "", None])
@@ -158,8 +158,13 @@ class FusedVAEStep:
             n_side[0] += 1
             return n_side[0] - 1
 
-        def pack(weight, p0, p1, Cs, Cb, split, Cs_pad=0):
-            pack_jobs.append(_lib.PackJob(weight.data_ptr(), p0.data_ptr() if p0 is not None else None,
+        # the batched weight re-pack (65 us, ~180 MB of traffic) also runs on the side stream, underneath the first
+        # encoder block, whose own (fp32, 3-channel) pack stays on the main stream; VP_SIDE_PACK=0 keeps it in line
+        k_pack = side_slot() if os.environ.get("VP_SIDE_PACK", "1") != "0" else None
+        first_pack_jobs = []
+
+        def pack(weight, p0, p1, Cs, Cb, split, Cs_pad=0, first=False):
+            (first_pack_jobs if (first and k_pack is not None) else pack_jobs).append(_lib.PackJob(weight.data_ptr(), p0.data_ptr() if p0 is not None else None,
                                           p1.data_ptr() if p1 is not None else None, Cs, Cb, Cs_pad, 1 if split else 0))
 
         def grad_of(p: torch.nn.Parameter) -> torch.Tensor:
@@ -203,6 +208,8 @@ class FusedVAEStep:
         enc_in_s = [None]        # split inputs
         enc_rec = []
         for i, blk in enumerate(enc.conv):
+            if i == 1 and k_pack is not None:
+                fwd.wait_side(k_pack)
             Cin, Cout, Hs = enc_ch[i], enc_ch[i + 1], sp[i + 1]
             n_out = B * Hs * Hs * Cout
             c = self._buf(f"enc{i}.c", n_out)
@@ -210,13 +217,13 @@ class FusedVAEStep:
             if enc16[i]:
                 p0 = self._sbuf(f"enc{i}.p0s", Cout * 25 * Cin)
                 p1 = self._sbuf(f"enc{i}.p1s", Cin * 25 * Cout)
-                pack(blk.conv.weight, p0, p1, Cout, Cin, True)
+                pack(blk.conv.weight, p0, p1, Cout, Cin, True, first=(i == 0))
                 fwd.add("vp_conv5_gather_bf16x3", P(enc_in_s[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
                         flops=fl, tag=f"enc{i}.fwd")
             else:
                 p0 = self._buf(f"enc{i}.p0", Cout * 25 * Cin)
                 p1 = self._buf(f"enc{i}.p1", Cin * 25 * Cout) if i > 0 else None
-                pack(blk.conv.weight, p0, p1, Cout, Cin, False)
+                pack(blk.conv.weight, p0, p1, Cout, Cin, False, first=(i == 0))
                 fwd.add("vp_conv5_gather_f32", P(enc_in[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
                         flops=fl, tag=f"enc{i}.fwd")
             # the activation feeds the next conv (+ its wgrad) or, for the last block, the flatten
@@ -227,6 +234,8 @@ class FusedVAEStep:
             enc_rec.append((blk, Cin, Cout, Hs, p1, c, mean, rstd, ws))
             enc_in.append(a)
             enc_in_s.append(a_s)
+        if L == 1 and k_pack is not None:
+            fwd.wait_side(k_pack)
         size = enc_ch[-1]
         F0 = 64 * size
         flat = self._buf("enc.flat", B * F0)
@@ -324,7 +333,7 @@ class FusedVAEStep:
         else:
             bwd.add("vp_bce_sigmoid_bwd_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), n_pix)
         ws_cs = self._ws("g.colsum.ws", lib.vp_colsum_workspace_bytes(B * S * S, C))
-        bwd.add("vp_colsum_f32", P(dlogit), P(grad_of(fin.bias)), B * S * S, C, P(ws_cs), ws_cs.numel() * 4)
+        bwd.add("vp_colsum_f32", P(dlogit), P(grad_of(fin.bias)), B * S * S, C, P(ws_cs), ws_cs.numel() * 4, side=side_slot())
         ws_wg = self._ws("g.wgrad.ws", self._max_wgrad_ws(enc_rec, dec_rec, Cf))
         bwd.add("vp_conv5_wgrad_f32", P(dec_in[-1]), P(dlogit), P(grad_of(fin.weight)), B, S, S, Cf, C, 1, P(ws_wg), ws_wg.numel() * 4,
                 flops=50.0 * B * S * S * Cf * C, tag="fin.wgrad", side=side_slot())   # reads dlogit / dec_in[-1]: both live on
@@ -430,7 +439,10 @@ class FusedVAEStep:
                     bwd.add("vp_conv5_scatter_f32", P(other), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
                             flops=fl, tag=f"enc{i}.dgrad")                                 # cur = d a_{i-1}
         self._pack_jobs = (_lib.PackJob * len(pack_jobs))(*pack_jobs)   # host array read by every call: keep it alive
-        fwd.add_first("vp_pack_w5_batch", self._pack_jobs, len(pack_jobs))
+        fwd.add_first("vp_pack_w5_batch", self._pack_jobs, len(pack_jobs), side=k_pack)
+        if first_pack_jobs:
+            self._pack_jobs0 = (_lib.PackJob * len(first_pack_jobs))(*first_pack_jobs)
+            fwd.add_first("vp_pack_w5_batch", self._pack_jobs0, len(first_pack_jobs))
         self._fwd, self._bwd_b = fwd, bwd
         self._n_side_events = n_side[0]
         self._bn_mods = [m for m in self.vae.modules() if hasattr(m, "num_batches_tracked")]
@@ -451,7 +463,7 @@ class FusedVAEStep:
         # instrumented steps run the serial schedule: an event pair around a kernel that shares the GPU with another
         # stream's kernels would time the mixture, not the kernel
         side = self._side_ctx() if timers is None else None
-        self._fwd.run(s, timers)
+        self._fwd.run(s, timers, side=side)
         self._bwd_dec.run(s, timers, side=side)
         if on_decoder_grads is not None:
             if side is not None:                         # the decoder's weight gradients are produced on the side stream
