@@ -134,6 +134,15 @@ int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hip
 using namespace vp;
 
 // VP_HALO=0 sends the narrow-channel layers back to the implicit-GEMM kernels (A/B runs)
+// XCD-aware tile order (igemm16.h): valid when the row-tile count is a multiple of 8 and there are >= 2 column tiles
+static int xcd_map_for(long M, long N, int gz) {
+  const char* e = getenv("VP_XCD_MAP");
+  if (e && atoi(e) == 0) return 0;
+  const Tile16 t = choose_tile16(M, N, gz);
+  const long gx = (M + t.bm - 1) / t.bm, gy = (N + t.bn - 1) / t.bn;
+  return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
+}
+
 static bool halo_enabled() {
   static const bool on = [] { const char* e = getenv("VP_HALO"); return !e || atoi(e) != 0; }();
   return on;
@@ -208,6 +217,7 @@ int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const 
   p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
   if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
+  p.xcd_map = xcd_map_for(p.M, p.N, p.nsplit);
   launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig);
   return check_launch("vp_conv5_gather_bf16x3");
 }
@@ -231,6 +241,7 @@ int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, flo
   if (p.nsplit == 2 &&
       hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
+  p.xcd_map = xcd_map_for(p.M, p.N, stride * stride * p.nsplit);
   launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
   return check_launch("vp_conv5_scatter_bf16x3");
 }

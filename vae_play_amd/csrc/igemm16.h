@@ -68,6 +68,7 @@ struct ProbF16 {
   const float* bias; float* out; const void* zero;
   ConvGeom g; int act; int M, N, K;
   int nsplit, k_per_split;   // nsplit == 2: both halves of K are atomically added onto a zeroed output
+  int xcd_map;               // remap (blockIdx.x, blockIdx.y) so that column tiles of one row tile share an XCD
   struct ZCtx { int k_begin, k_end; };
   struct ARow { int pix_base, h0, w0, valid; };
   struct BRow { int off, valid; };
@@ -153,6 +154,7 @@ struct ProbT16 {
   const u16* w; size_t w_plane;          // packed P1 planes [Cb][25][Cs]
   float* out; const void* zero; ConvGeom g; int M, N;
   int nsplit;                // 1, or 2: z = phase*2 + half, halves atomically added onto a zeroed output
+  int xcd_map;
   struct ZCtx { int k_begin, k_end, ph, pw, th, tw; };
   struct ARow { int pix_base, q, p, valid; };
   struct BRow { int off, valid; };
@@ -343,7 +345,18 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int tx = blockIdx.x, ty = blockIdx.y;
+  if constexpr (!P::A_KM) {
+    if (p.xcd_map) {
+      // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs in launch order; give the gridDim.y
+      // column tiles that read the same activation rows hardware ids that are equal modulo 8 (same XCD, same L2)
+      const int hid = blockIdx.x + gridDim.x * blockIdx.y;
+      const int r = hid & 7, q = hid >> 3;
+      tx = r + 8 * (q / (int)gridDim.y);
+      ty = q % (int)gridDim.y;
+    }
+  }
+  const int m0 = tx * BM, n0 = ty * BN;
 
   typename P::ZCtx z;
   p.z_setup(blockIdx.z, z);
