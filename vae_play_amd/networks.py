@@ -261,6 +261,35 @@ class Discriminator(nn.Module):
         ten = F_hip.flatten_nchw(ten)
         return F_hip.activation(self.fc(ten), "sigmoid")
 
+    def forward_rec_and_gan(self, ten_orig, ten_predicted, ten_sampled):
+        """Both results of ``forward(..., "REC")`` and ``forward(..., "GAN")`` from ONE pass over the conv stack.
+        In training mode the two reference calls compute identical activations (BatchNorm normalises with the batch
+        statistics) and differ only in side effects: the blocks up to ``recon_levl`` update their running statistics
+        twice.  That second update is replayed here from the buffers before / after the single pass
+        (rm2 = (1-m) rm1 + (rm1 - (1-m) rm0)), and ``num_batches_tracked`` is advanced twice."""
+        ten = torch.cat((ten_orig, ten_predicted, ten_sampled), 0)
+        layer_ten = None
+        replay = []
+        for i, lay in enumerate(self.conv):
+            if i == self.recon_levl:
+                bn = lay.bn
+                if self.training:
+                    replay.append((bn, bn.running_mean.clone(), bn.running_var.clone()))
+                ten, tap = lay(ten, True)
+                layer_ten = F_hip.flatten_nchw(tap)
+            else:
+                if self.training and 0 < i < self.recon_levl:
+                    replay.append((lay.bn, lay.bn.running_mean.clone(), lay.bn.running_var.clone()))
+                ten = lay(ten)
+        with torch.no_grad():
+            for bn, rm0, rv0 in replay:
+                k = 1.0 - bn.momentum
+                bn.running_mean.mul_(2.0 - bn.momentum).sub_(rm0, alpha=k)        # (1-m) rm1 + rm1 - (1-m) rm0
+                bn.running_var.mul_(2.0 - bn.momentum).sub_(rv0, alpha=k)
+                bn.num_batches_tracked.add_(1)
+        ten = F_hip.flatten_nchw(ten)
+        return layer_ten, F_hip.activation(self.fc(ten), "sigmoid")
+
 
 class VaeGan(nn.Module):
     """models/networks.py:201-281: Encoder(channel_in=1) / Decoder(channel_out=1) / Discriminator / DirectDecoder.
@@ -278,6 +307,9 @@ class VaeGan(nn.Module):
         self.decoder = Decoder(z_size=self.z_size, size=self.encoder.size, channel_out=1, iter_level=self.iter_level)
         self.discriminator = Discriminator(channel_in=1, recon_level=self.iter_level, iter_level=self.iter_level)
         self.param_encoder = DirectDecoder(z_size, num_of_param=num_of_param)
+        # the reference runs the discriminator twice per step ("REC" then "GAN", models/networks.py:244-245); one pass
+        # gives both (Discriminator.forward_rec_and_gan).  Set to False for the literal two-call sequence.
+        self.single_pass_discriminator = True
         self.init_parameters()
 
     def init_parameters(self):
@@ -297,8 +329,11 @@ class VaeGan(nn.Module):
                 z_p = torch.randn(len(x), self.z_size, device=dev)
             z_p = z_p.detach().requires_grad_(True)
             x_p = self.decoder(z_p)
-            disc_layer = self.discriminator(x, x_tilde, x_p, "REC")
-            disc_class = self.discriminator(x, x_tilde, x_p, "GAN")
+            if self.single_pass_discriminator and self.discriminator.recon_levl < len(self.discriminator.conv):
+                disc_layer, disc_class = self.discriminator.forward_rec_and_gan(x, x_tilde, x_p)
+            else:
+                disc_layer = self.discriminator(x, x_tilde, x_p, "REC")
+                disc_class = self.discriminator(x, x_tilde, x_p, "GAN")
             return x_tilde, disc_class, disc_layer, mus, log_variances, params
         if x is None:
             if z_p is None:
