@@ -409,7 +409,9 @@ class FusedVAEStep:
                     P(ws), ws.numel() * 4)
 
         bn_block_bwd2(h, dhb_a, dh, B, 1024, fc_bn, h_mean, h_rstd, h_ws)
+        self._bwd_b_fc_wgrad = len(bwd.calls)        # this call is replaced by the factored exchange in multi-rank steps
         bwd.add("vp_gemm_f32", P(dh), 1, 1024, P(flat), 1, F0, P(grad_of(fc_lin.weight)), F0, None, 1024, F0, B, 2, P(ws_g1), wsn)
+        self._fc_factors = (dh, flat, fc_lin.weight, F0)
         bwd.add("vp_gemm_f32", P(dh), 1024, 1, P(fc_lin.weight), 1, F0, P(gA), F0, None, B, F0, 1024, 1, P(ws_g1), wsn)
         # the encoder's dense gradients (fc.0 = 134 MB at config 3, fc.1, l_mu, l_var) are final and its dense
         # parameters are not read any more: second bucket
@@ -458,12 +460,15 @@ class FusedVAEStep:
         return n
 
     # ---- execution ---------------------------------------------------------------------------
-    def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None, on_dense_grads=None):
+    def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None, on_dense_grads=None, on_fc_wgrad=None,
+                    after_forward=None):
         s = torch.cuda.current_stream().cuda_stream
         # instrumented steps run the serial schedule: an event pair around a kernel that shares the GPU with another
         # stream's kernels would time the mixture, not the kernel
         side = self._side_ctx() if timers is None else None
         self._fwd.run(s, timers, side=side)
+        if after_forward is not None:
+            after_forward()
         self._bwd_dec.run(s, timers, side=side)
         if on_decoder_grads is not None:
             if side is not None:                         # the decoder's weight gradients are produced on the side stream
@@ -471,7 +476,12 @@ class FusedVAEStep:
             on_decoder_grads()
         self._bwd_a.run(s, timers)
         self._dhb[0].add_(self._dhb[1])          # d hb = dgrad(mu head) + dgrad(logvar head)  (B x 1024)
-        self._bwd_b.run(s, timers, 0, self._bwd_b_dense_done)
+        if on_fc_wgrad is not None:
+            self._bwd_b.run(s, timers, 0, self._bwd_b_fc_wgrad)
+            on_fc_wgrad()                                     # computes the fc.0 weight gradient from gathered factors
+            self._bwd_b.run(s, timers, self._bwd_b_fc_wgrad + 1, self._bwd_b_dense_done)
+        else:
+            self._bwd_b.run(s, timers, 0, self._bwd_b_dense_done)
         if on_dense_grads is not None:
             on_dense_grads()
         self._bwd_b.run(s, timers, self._bwd_b_dense_done, side=side)
@@ -488,7 +498,7 @@ class FusedVAEStep:
         return self._side
 
     def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None,
-                         on_dense_grads=None):
+                         on_dense_grads=None, on_fc_wgrad=None, after_forward=None):
         """Gradients of (BCE_sum + KL_sum)/B land in the optimiser's flat gradient arena.
         Returns (loss, recon, kl) as device scalars (no host sync).  ``timers`` =
         {"names": set of entry points, "events": []} brackets those launches with HIP events
@@ -497,10 +507,11 @@ class FusedVAEStep:
             self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
         self.x_nchw.copy_(x, non_blocking=True)
         self.eps.copy_(eps, non_blocking=True)
-        if self._graph is not None and timers is None and on_decoder_grads is None and on_dense_grads is None:
+        if self._graph is not None and timers is None and on_decoder_grads is None and on_dense_grads is None \
+                and on_fc_wgrad is None and after_forward is None:
             self._graph.replay()
         else:
-            self._launch_all(timers, on_decoder_grads, on_dense_grads)
+            self._launch_all(timers, on_decoder_grads, on_dense_grads, on_fc_wgrad, after_forward)
         # BatchNorm num_batches_tracked is advanced lazily in sync_counters()
         self._steps_since_sync = getattr(self, "_steps_since_sync", 0) + 1
         return self._loss_num / self.B, self.recon, self.kl_sum
@@ -550,10 +561,41 @@ class FusedVAEStep:
             cut = self._decoder_slice_start()
             dense = self._encoder_dense_start()
             works = []
-            out = self.forward_backward(
-                x, eps, timers,
-                on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)),
-                on_dense_grads=lambda: works.append(parallel.allreduce_flat_grads(g[dense:cut], self.group, async_op=True)))
+            factored = os.environ.get("VP_DP_FACTORED", "1") != "0"
+            if factored:
+                # fc.0's weight gradient (134 MB of the 213 MB at config 3) is dW = dh^T flat, a sum of B outer products
+                # per rank: exchange the two factors (W x 4.3 MB all-gather) and contract over all W*B rows locally
+                # instead of all-reducing the weight-sized result.  Identical to the sum of the ranks' gradients.
+                dh, flat, fcw, F0 = self._fc_factors
+                W, B = self.world, self.B
+                if not hasattr(self, "_fc_all"):
+                    self._fc_all = (torch.empty((W * B, 1024), device=self.dev), torch.empty((W * B, F0), device=self.dev))
+                dh_all, flat_all = self._fc_all
+                gather = []
+                fc_lo = self.opt.arena.offsets[[id(p) for p in self.opt.arena.params].index(id(fcw))]
+                fc_hi = fc_lo + (fcw.numel() + 63) // 64 * 64
+
+                def after_fwd():
+                    gather.append(parallel.allgather_rows(flat_all, flat.view(B, F0), self.group, async_op=True))
+
+                def fc_wgrad():
+                    w2 = parallel.allgather_rows(dh_all, dh.view(B, 1024), self.group, async_op=True)
+                    for w in gather + [w2]:
+                        w.wait()
+                    ops.gemm(dh_all, 1, 1024, flat_all, 1, F0, 1024, F0, W * B, 2, out=fcw.grad.view(1024, F0))
+
+                def dense_bucket():
+                    assert fc_lo == dense, "fc.0.weight must open the encoder's dense slice"
+                    works.append(parallel.allreduce_flat_grads(g[fc_hi:cut], self.group, async_op=True))
+
+                out = self.forward_backward(
+                    x, eps, timers, after_forward=after_fwd, on_fc_wgrad=fc_wgrad, on_dense_grads=dense_bucket,
+                    on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)))
+            else:
+                out = self.forward_backward(
+                    x, eps, timers,
+                    on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)),
+                    on_dense_grads=lambda: works.append(parallel.allreduce_flat_grads(g[dense:cut], self.group, async_op=True)))
             works.append(parallel.allreduce_flat_grads(g[:dense], self.group, async_op=True))
             for w in works:
                 if w is not None:

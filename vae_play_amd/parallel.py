@@ -48,6 +48,16 @@ def allreduce_flat_grads(flat_grad: torch.Tensor, group=None, async_op: bool = F
     return None
 
 
+def allgather_rows(out_all: torch.Tensor, local: torch.Tensor, group=None, async_op: bool = False):
+    """out_all[(r*B):(r+1)*B] = rank r's ``local`` (B rows).  Used to exchange the two rank-B factors of a dense
+    layer's weight gradient (dW = dY^T X) instead of all-reducing the weight-sized gradient itself."""
+    if dist.get_backend(group) == "nccl":          # RCCL writes straight into the gathered buffer
+        return dist.all_gather_into_tensor(out_all, local.contiguous(), group=group, async_op=async_op)
+    world = dist.get_world_size(group)
+    chunks = list(out_all.view(world, *local.shape).unbind(0))
+    return dist.all_gather(chunks, local, group=group, async_op=async_op)
+
+
 def broadcast_flat_params(flat_param: torch.Tensor, src: int = 0, group=None) -> None:
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_param, src=src, group=group)
