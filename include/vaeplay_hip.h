@@ -205,6 +205,13 @@ int vp_be_loss_fwd_f32(const float* logits, const float* targets, float* loss, f
 int vp_be_loss_bwd_f32(const float* logits, const float* targets, const float* sums, const float* gptr, float* dlogits, int B,
                        int n, float bce_weight, float smooth, vp_stream stream);
 
+/* plain dice loss on probabilities (tools/ops.py:178-185, used by edge_loss :187-215): 1 - mean_b (2 I_b + s)/(P_b + T_b + s);
+ * sums[B][4] as above (entry 0 unused); workspace = vp_be_loss_workspace_bytes(B, n). */
+int vp_dice_loss_fwd_f32(const float* probs, const float* targets, float* loss, float* sums, int B, int n, float smooth, void* ws,
+                         size_t ws_bytes, vp_stream stream);
+int vp_dice_loss_bwd_f32(const float* probs, const float* targets, const float* sums, const float* gptr, float* dprobs, int B, int n,
+                         float smooth, vp_stream stream);
+
 /* ---- 0.5*(a-b)^2 (VaeGan.loss, models/networks.py:267 "nle" per element, :273 "mse" summed per row) ---- */
 int vp_half_sqdiff_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream);
 /* out[r] = sum_j 0.5*(a[r][j]-b[r][j])^2 for R contiguous rows of n_per_row elements */

@@ -128,6 +128,77 @@ def aux_fixture(blocks, Cin, target, B, H):
     return fx
 
 
+def gan_disc_fixture(blocks, in_size, B):
+    """models/networks_BE_GAN.py:74-139 assembled from the reference's own blocks; forward + backward."""
+    import math
+
+    def mapper(cin, max_channel):
+        m = nn.Module()
+        m.convs = nn.Sequential(blocks.Conv2d(cin, 16, 3, 2, bn=None, activate="lrelu"), blocks.Conv2d(16, 32, 3, 2, bn=None, activate="lrelu"))
+        c, nxt = 32, min(64, max_channel)
+        m.feat_modules = nn.ModuleList()
+        for _ in range(int(math.log2(in_size // 16)) - 2):
+            m.feat_modules.append(nn.Sequential(blocks.Conv2d(c, nxt, 3, 2, bn="batch", activate="lrelu"),
+                                                blocks.Conv2d(nxt, nxt, 3, 1, bn="batch", activate="lrelu")))
+            c, nxt = nxt, min(nxt * 2, max_channel)
+        m.pooler = nn.Sequential(blocks.Conv2d(c, max_channel, 1, 1, bn=None, activate=None), nn.AdaptiveAvgPool2d((1, 1)))
+
+        def run(x, msk):
+            x = m.convs(torch.cat([x, msk], dim=1))
+            feats = []
+            for idx, mod in enumerate(m.feat_modules):
+                x = mod(x)
+                feats.append(x.reshape(x.size(0), -1) * (idx // 2 + 1))
+            x = m.pooler(x)
+            return x.reshape(x.size(0), -1), torch.cat(feats, dim=1)
+        m.run = run
+        return m
+
+    d = nn.Module()
+    d.content_disc, d.boundary_disc = mapper(2, 64), mapper(2, 64)
+    d.predictor = nn.Sequential(blocks.Linear(128, 128, bias=True, activate="lrelu"), blocks.Linear(128, 64, bias=True, activate="lrelu"),
+                                blocks.Linear(64, 5, bias=False, activate=None))
+    d.load_state_dict(BE.seeded_weights(d.state_dict(), 444))
+    d.train()
+    g = torch.Generator().manual_seed(29)
+    x = torch.rand(B, 3, in_size, in_size, generator=g)
+    m1 = torch.rand(B, 1, in_size, in_size, generator=g).requires_grad_(True)
+    m2 = torch.rand(B, 1, in_size, in_size, generator=g).requires_grad_(True)
+    x0 = x[:, 0, :, :].reshape(B, 1, in_size, in_size)
+    a, fa = d.content_disc.run(x0, m1)
+    b, fb = d.boundary_disc.run(x0, m2)
+    logits, feats = d.predictor(torch.cat([a, b], dim=1)), torch.cat([fa, fb], dim=1)
+    gl, gf = torch.randn(logits.shape, generator=g), torch.randn(feats.shape, generator=g) * 0.01
+    ((logits * gl).sum() + (feats * gf).sum()).backward()
+    p = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    for k in p:
+        if k.endswith("running_mean"):
+            p[k] = torch.zeros_like(p[k])
+        elif k.endswith("running_var"):
+            p[k] = torch.ones_like(p[k])
+        elif k.endswith("num_batches_tracked"):
+            p[k] = torch.zeros_like(p[k])
+    O.require_grad(p)
+    m1o, m2o = m1.detach().clone().requires_grad_(True), m2.detach().clone().requires_grad_(True)
+    lo, fo = BE.gan_discriminator_forward(p, x, m1o, m2o, in_size, True)
+    ((lo * gl).sum() + (fo * gf).sum()).backward()
+    bit_equal(lo.detach(), logits.detach(), "gan disc logits")
+    bit_equal(fo.detach(), feats.detach(), "gan disc feats")
+    bit_equal(m1o.grad, m1.grad, "gan disc dm1")
+    bit_equal(m2o.grad, m2.grad, "gan disc dm2")
+    fx = {"meta_S": in_size, "meta_B": B, "weight_seed": np.array(444), "x": np_(x), "m1": np_(m1), "m2": np_(m2), "logits": np_(logits),
+          "feats_stride7": np_(feats.detach().flatten()[::7][:8192]), "gl": np_(gl), "gf": np_(gf), "dm1": np_(m1.grad), "dm2": np_(m2.grad)}
+    rsd = d.state_dict(keep_vars=True)
+    for n in O.trainable_names(p):
+        bit_equal(p[n].grad, rsd[n].grad, f"gan disc grad {n}")
+        fx[f"grad/{n}"] = np_(rsd[n].grad)
+    for n in p:
+        if "running" in n:
+            bit_equal(p[n], rsd[n], f"gan disc bn {n}")
+            fx[f"bn/{n}"] = np_(p[n])
+    return fx
+
+
 def main():
     _, blocks = import_reference()
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -139,6 +210,7 @@ def main():
 
     save("be_heads_c32_b2_h16", heads_fixture(blocks, 32, 2, 16, 2))
     save("be_aux_c128_to32", aux_fixture(blocks, 128, 32, 2, 12))
+    save("be_gan_disc128_b2", gan_disc_fixture(blocks, 128, 2))
     print("oracle == reference blocks composition (bit-exact) on every BE fixture")
 
 

@@ -113,3 +113,46 @@ def heads_step(p: Params, opt, feature: torch.Tensor, bimgs: torch.Tensor, eimgs
     if opt is not None:
         opt.step()
     return {"masks": masks.detach(), "edges": edges.detach(), "loss_edge": loss_edge.detach(), "loss_mask": loss_mask.detach()}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# models/networks_BE_GAN.py (the discriminator built on blocks) and the losses of train_BE_GAN.py:131-160.
+# Pinning: as for the heads above -- the networks are rebuilt from the reference's own blocks classes by
+# oracle/gen_golden_be.py (networks_BE_GAN.py imports torchvision); edge_loss / dice_loss are restated (tools/ops.py
+# needs cv2): parity unpinned for those two.
+# --------------------------------------------------------------------------------------------------------------------
+def mask_mapper_forward(p: Params, prefix: str, x: torch.Tensor, m: torch.Tensor, in_size: int, training: bool = True):
+    """models/networks_BE_GAN.py:101-112."""
+    repeat = int(math.log2(in_size // 16)) - 2
+    x = torch.cat([x, m], dim=1)
+    x = O.blocks_conv2d(p, prefix + "convs.0.", x, 3, 2, None, "lrelu", training)
+    x = O.blocks_conv2d(p, prefix + "convs.1.", x, 3, 2, None, "lrelu", training)
+    feats = []
+    for i in range(repeat):
+        x = O.blocks_conv2d(p, f"{prefix}feat_modules.{i}.0.", x, 3, 2, "batch", "lrelu", training)
+        x = O.blocks_conv2d(p, f"{prefix}feat_modules.{i}.1.", x, 3, 1, "batch", "lrelu", training)
+        feats.append(x.reshape(x.size(0), -1) * (i // 2 + 1))
+    feats = torch.cat(feats, dim=1)
+    x = O.blocks_conv2d(p, prefix + "pooler.0.", x, 1, 1, None, None, training)
+    x = F.adaptive_avg_pool2d(x, (1, 1))
+    return x.reshape(x.size(0), -1), feats
+
+
+def gan_discriminator_forward(p: Params, x: torch.Tensor, m1: torch.Tensor, m2: torch.Tensor, in_size: int, training: bool = True,
+                              prefix: str = ""):
+    """models/networks_BE_GAN.py:129-139."""
+    x = x[:, 0, :, :].reshape(x.size(0), 1, x.size(2), x.size(3))
+    a, fa = mask_mapper_forward(p, prefix + "content_disc.", x, m1, in_size, training)
+    b, fb = mask_mapper_forward(p, prefix + "boundary_disc.", x, m2, in_size, training)
+    h = torch.cat([a, b], dim=1)
+    h = O.blocks_linear(p, prefix + "predictor.0.", h, "lrelu")
+    h = O.blocks_linear(p, prefix + "predictor.1.", h, "lrelu")
+    return O.blocks_linear(p, prefix + "predictor.2.", h, None), torch.cat([fa, fb], dim=1)
+
+
+def edge_loss(mask_probs: torch.Tensor, mask_targets: torch.Tensor) -> torch.Tensor:
+    """tools/ops.py:187-215 (restated; parity unpinned)."""
+    k = torch.full((3, 3), -1.0)
+    k[1, 1] = 8.0
+    k = (k / 8).reshape(1, 1, 3, 3)
+    return dice_loss(F.conv2d(mask_probs, k, padding=1).abs(), F.conv2d(mask_targets, k, padding=1).abs())

@@ -100,3 +100,54 @@ def test_compose_net_forward_shapes():
     net = N.initialize_model(N.ComposeNet(N.FeatureNet(None, in_channels=64, target_out_channels=32))).to(DEV).train()
     out = net(torch.randn(2, 64, 16, 16, device=DEV))
     assert tuple(out["masks"].shape) == (2, 1, 64, 64) and tuple(out["edges"].shape) == (2, 1, 64, 64)
+
+
+def test_gan_discriminator_against_reference_golden():
+    """models/networks_BE_GAN.py:74-139 (MaskMapper x2 + Linear head): logits, feature vector, both mask gradients, every
+    parameter gradient and the BatchNorm buffers against the reference's own blocks."""
+    from oracle import ref_be as BE
+    import vae_play_amd.networks_BE_GAN as NG
+    g = load_golden("be_gan_disc128_b2")
+    S = int(g["meta_S"])
+    d = NG.Discriminator(3, S, 5)
+    d.load_state_dict(BE.seeded_weights(d.state_dict(), int(g["weight_seed"])))
+    d = d.to(DEV).train()
+    x = dev(t(g["x"]))
+    m1, m2 = dev(t(g["m1"])).requires_grad_(True), dev(t(g["m2"])).requires_grad_(True)
+    logits, feats = d(x, m1, m2)
+    assert_close(logits, t(g["logits"]), NORTH_STAR_RTOL, "logits")
+    assert_close(feats.detach().cpu().flatten()[::7][:8192], t(g["feats_stride7"]), NORTH_STAR_RTOL, "feats[::7]")
+    ((logits * dev(t(g["gl"]))).sum() + (feats * dev(t(g["gf"]))).sum()).backward()
+    assert_close(m1.grad, t(g["dm1"]), NORTH_STAR_RTOL * 5, "dm1")
+    assert_close(m2.grad, t(g["dm2"]), NORTH_STAR_RTOL * 5, "dm2")
+    for n, p in d.named_parameters():
+        assert_close(p.grad, t(g[f"grad/{n}"]), NORTH_STAR_RTOL * 5, f"grad {n}")
+    sd = d.state_dict()
+    for k in g:
+        if k.startswith("bn/"):
+            assert_close(sd[k[3:]], t(g[k]), NORTH_STAR_RTOL, f"running stat {k[3:]}")
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 32, 32), (3, 1, 24, 40)])
+def test_dice_and_edge_losses_match_oracle(shape):
+    from oracle import ref_be as BE
+    from vae_play_amd import functional as Fh
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    p = torch.rand(shape, generator=g)
+    tt = (torch.rand(shape, generator=g) > 0.5).float()
+    for name, fo, fd in (("dice", BE.dice_loss, Fh.dice_loss), ("edge", BE.edge_loss, Fh.edge_loss)):
+        po = p.clone().requires_grad_(True)
+        lo = fo(po, tt)
+        lo.backward()
+        pd = dev(p).requires_grad_(True)
+        ld = fd(pd, dev(tt))
+        ld.backward()
+        assert abs(ld.item() - lo.item()) <= 5e-6 * abs(lo.item()) + 1e-7, (name, ld.item(), lo.item())
+        assert_close(pd.grad, po.grad, 5e-5, f"d {name}_loss / d p")
+
+
+def test_be_gan_generator_forward_shapes():
+    import vae_play_amd.networks_BE_GAN as NG
+    net = NG.ComposeNet(3, 64, backbone=None, feature_channels=128).to(DEV).train()
+    out = net(torch.randn(2, 128, 16, 16, device=DEV))
+    assert tuple(out["masks"].shape) == (2, 1, 64, 64) and tuple(out["edges"].shape) == (2, 1, 64, 64)

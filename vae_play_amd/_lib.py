@@ -80,6 +80,8 @@ SIGNATURES = {
     "vp_be_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vp_be_loss_fwd_f32": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, P, c_size_t, P]),
     "vp_be_loss_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, P]),
+    "vp_dice_loss_fwd_f32": (c_int, [P, P, P, P, c_int, c_int, c_float, P, c_size_t, P]),
+    "vp_dice_loss_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
     "vp_half_sqdiff_f32": (c_int, [P, P, P, c_size_t, P]),
     "vp_half_sqdiff_rowsum_f32": (c_int, [P, P, P, c_int, c_int, P]),
     "vp_half_sqdiff_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),

@@ -173,6 +173,8 @@ __global__ void half_sqdiff_bwd_kernel(const float* __restrict__ a, const float*
 // Two stages (chunk partials in fp32 lanes -> fp64 tree, then a fixed-order fp64 sum over chunks): bit-reproducible.
 constexpr int BE_CHUNK = 4096;
 
+// PROBS: x already holds probabilities (plain dice loss, tools/ops.py:178-185): no sigmoid, no BCE term
+template <bool PROBS>
 __global__ void __launch_bounds__(256) be_loss_partial_kernel(const float* __restrict__ x, const float* __restrict__ t,
                                                               double* __restrict__ part, int n, int nchunk) {
   __shared__ double sh[4][4];
@@ -182,9 +184,12 @@ __global__ void __launch_bounds__(256) be_loss_partial_kernel(const float* __res
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = i0 + threadIdx.x; i < i1; i += 256) {
     const float xv = x[base + i], tv = t[base + i];
-    const float e = __expf(-fabsf(xv));
-    const float p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-    s[0] += fmaxf(xv, 0.f) - xv * tv + log1pf(e);
+    float p = xv;
+    if constexpr (!PROBS) {
+      const float e = __expf(-fabsf(xv));
+      p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      s[0] += fmaxf(xv, 0.f) - xv * tv + log1pf(e);
+    }
     s[1] += p * tv;
     s[2] += p;
     s[3] += tv;
@@ -221,6 +226,7 @@ __global__ void be_loss_final_kernel(const double* __restrict__ part, float* __r
 }
 
 // dx_i = g * [ w/(B n) (p_i - t_i) + (a_b t_i + b_b) p_i (1 - p_i) ],  D = P + T + s, a_b = -2/(B D), b_b = (2 I + s)/(B D^2)
+template <bool PROBS>
 __global__ void be_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ sums,
                                    const float* __restrict__ gptr, float* __restrict__ dx, int B, int n, float bce_weight,
                                    float smooth) {
@@ -232,9 +238,13 @@ __global__ void be_loss_bwd_kernel(const float* __restrict__ x, const float* __r
   const size_t base = (size_t)b * n;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float xv = x[base + i], tv = t[base + i];
-    const float e = __expf(-fabsf(xv));
-    const float p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-    dx[base + i] = cb * (p - tv) + (ab * tv + bb) * p * (1.f - p);
+    if constexpr (PROBS) {
+      dx[base + i] = ab * tv + bb;
+    } else {
+      const float e = __expf(-fabsf(xv));
+      const float p = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      dx[base + i] = cb * (p - tv) + (ab * tv + bb) * p * (1.f - p);
+    }
   }
 }
 
@@ -631,7 +641,7 @@ int vp_be_loss_fwd_f32(const float* logits, const float* targets, float* loss, f
   if (ws_bytes < vp_be_loss_workspace_bytes(B, n)) return fail(VP_ERR_WORKSPACE, "vp_be_loss_fwd_f32: workspace too small");
   const int nchunk = (n + BE_CHUNK - 1) / BE_CHUNK;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(be_loss_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, logits, targets, (double*)ws, n, nchunk);
+  hipLaunchKernelGGL((be_loss_partial_kernel<false>), dim3(nchunk, B), dim3(256), 0, s, logits, targets, (double*)ws, n, nchunk);
   int rc = check_launch("vp_be_loss_fwd_f32(partial)");
   if (rc) return rc;
   hipLaunchKernelGGL(be_loss_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, sums, loss, B, n, nchunk, bce_weight, smooth);
@@ -641,9 +651,30 @@ int vp_be_loss_fwd_f32(const float* logits, const float* targets, float* loss, f
 int vp_be_loss_bwd_f32(const float* logits, const float* targets, const float* sums, const float* gptr, float* dlogits, int B,
                        int n, float bce_weight, float smooth, vp_stream stream) {
   VP_REQUIRE(logits && targets && sums && dlogits && B > 0 && n > 0, "vp_be_loss_bwd_f32: bad arguments");
-  hipLaunchKernelGGL(be_loss_bwd_kernel, dim3(grid_for((size_t)n, 256, 256), B), dim3(256), 0, (hipStream_t)stream, logits, targets,
-                     sums, gptr, dlogits, B, n, bce_weight, smooth);
+  hipLaunchKernelGGL((be_loss_bwd_kernel<false>), dim3(grid_for((size_t)n, 256, 256), B), dim3(256), 0, (hipStream_t)stream, logits,
+                     targets, sums, gptr, dlogits, B, n, bce_weight, smooth);
   return check_launch("vp_be_loss_bwd_f32");
+}
+
+int vp_dice_loss_fwd_f32(const float* probs, const float* targets, float* loss, float* sums, int B, int n, float smooth, void* ws,
+                         size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(probs && targets && loss && sums && ws && B > 0 && n > 0, "vp_dice_loss_fwd_f32: bad arguments");
+  if (ws_bytes < vp_be_loss_workspace_bytes(B, n)) return fail(VP_ERR_WORKSPACE, "vp_dice_loss_fwd_f32: workspace too small");
+  const int nchunk = (n + BE_CHUNK - 1) / BE_CHUNK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((be_loss_partial_kernel<true>), dim3(nchunk, B), dim3(256), 0, s, probs, targets, (double*)ws, n, nchunk);
+  int rc = check_launch("vp_dice_loss_fwd_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(be_loss_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, sums, loss, B, n, nchunk, 0.f, smooth);
+  return check_launch("vp_dice_loss_fwd_f32(final)");
+}
+
+int vp_dice_loss_bwd_f32(const float* probs, const float* targets, const float* sums, const float* gptr, float* dprobs, int B, int n,
+                         float smooth, vp_stream stream) {
+  VP_REQUIRE(probs && targets && sums && dprobs && B > 0 && n > 0, "vp_dice_loss_bwd_f32: bad arguments");
+  hipLaunchKernelGGL((be_loss_bwd_kernel<true>), dim3(grid_for((size_t)n, 256, 256), B), dim3(256), 0, (hipStream_t)stream, probs,
+                     targets, sums, gptr, dprobs, B, n, 0.f, smooth);
+  return check_launch("vp_dice_loss_bwd_f32");
 }
 
 int vp_half_sqdiff_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream) {

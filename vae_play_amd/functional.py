@@ -458,6 +458,23 @@ class _BELoss(Function):
         return ops.be_loss_bwd(logits, targets, sums, g.reshape(1).contiguous(), ctx.w, ctx.smooth), None, None, None
 
 
+class _DiceLoss(Function):
+    """1 - mean_b (2 sum(p t) + s) / (sum p + sum t + s) on probabilities (no gradient to the targets)."""
+
+    @staticmethod
+    def forward(ctx, probs, targets, smooth: float):
+        probs, targets = probs.contiguous(), targets.contiguous()
+        loss, sums = ops.dice_loss_fwd(probs, targets, smooth)
+        ctx.smooth = smooth
+        ctx.save_for_backward(probs, targets, sums)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, targets, sums = ctx.saved_tensors
+        return ops.dice_loss_bwd(probs, targets, sums, g.reshape(1).contiguous(), ctx.smooth), None, None
+
+
 class _HalfSqDiff(Function):
     """0.5*(a-b)^2 per element ("nle", models/networks.py:267) or summed over all but the first dim (":273")."""
 
@@ -564,6 +581,31 @@ def be_loss(logits, targets, bce_weight: float = 0.5, smooth: float = 1.0):
     """train_BE.py:58-59: ``bce_weight * F.binary_cross_entropy_with_logits(logits, targets)
     + compute_dice_loss(logits.sigmoid(), targets)`` (tools/ops.py:12-19) for (B, ...) logits; scalar."""
     return _BELoss.apply(logits, targets, bce_weight, smooth)
+
+
+def dice_loss(probs, targets, smooth: float = 1.0):
+    """tools/ops.py:12-19 / :178-185 on probabilities."""
+    return _DiceLoss.apply(probs, targets, smooth)
+
+
+_EDGE_KERNEL = None
+
+
+def edge_loss(mask_probs, mask_targets):
+    """tools/ops.py:187-215: dice loss between |Laplacian| edge maps of prediction and target (single-channel maps;
+    3x3 kernel [[-1,-1,-1],[-1,8,-1],[-1,-1,-1]] / 8, zero padding).  The filter is a fixed-weight 3x3 convolution on the
+    HIP conv kernel; |e| = relu(e) + relu(-e) (the activation kernels differentiate through their OUTPUT, so an
+    even function has to be assembled from monotone pieces)."""
+    global _EDGE_KERNEL
+    if _EDGE_KERNEL is None or _EDGE_KERNEL.device != mask_probs.device:
+        k = torch.full((3, 3), -1.0)
+        k[1, 1] = 8.0
+        _EDGE_KERNEL = (k / 8).reshape(1, 1, 3, 3).to(mask_probs.device)
+    def absmap(x):
+        e = conv2d(x, _EDGE_KERNEL, None, 1)
+        return activation(e, "relu") + activation(-e, "relu")
+
+    return dice_loss(absmap(mask_probs), absmap(mask_targets).detach())
 
 
 def half_sq_diff(a, b):

@@ -330,6 +330,22 @@ def be_loss_bwd(logits, targets, sums, g, bce_weight: float, smooth: float):
     return dx
 
 
+def dice_loss_fwd(probs, targets, smooth: float):
+    B, n = probs.shape[0], probs.numel() // probs.shape[0]
+    loss = torch.empty(1, dtype=torch.float32, device=probs.device)
+    sums = torch.empty((B, 4), dtype=torch.float32, device=probs.device)
+    ws = _ws(_lib.load().vp_be_loss_workspace_bytes(B, n), probs)
+    _lib.call("vp_dice_loss_fwd_f32", _p(probs), _p(targets), _p(loss), _p(sums), B, n, smooth, _p(ws), ws.numel() * 4, _stream())
+    return loss, sums
+
+
+def dice_loss_bwd(probs, targets, sums, g, smooth: float):
+    B, n = probs.shape[0], probs.numel() // probs.shape[0]
+    dp = torch.empty_like(probs)
+    _lib.call("vp_dice_loss_bwd_f32", _p(probs), _p(targets), _p(sums), _p(g), _p(dp), B, n, smooth, _stream())
+    return dp
+
+
 def half_sqdiff(a, b):
     out = torch.empty_like(a)
     _lib.call("vp_half_sqdiff_f32", _p(a), _p(b), _p(out), a.numel(), _stream())
