@@ -7,7 +7,8 @@
 // stages the input pixels of its output tile ONCE, halo included, and serves all 25 taps from LDS: a tap
 // is just a per-lane address offset of the A-fragment read.
 //
-//   out[pix][n] = sum_{tap=(r,q)} sum_{c<CB} in[pixel(pix) + off(tap)][c] * w[n][tap][c]
+//   out[pix][n] = sum_{tap=(r,q)} sum_{c<Cin} in[pixel(pix) + off(tap)][c] * w[n][tap][c]
+//   (Cin is swept in chunks of CB channels; the halo tile of one chunk is staged once and serves all 25 taps)
 //
 //   * gather, stride S in {1, 2} (Conv2d forward, ConvTranspose2d input gradient):
 //       in = the big tensor, pixel = S*(y, x) - 2, off = (r, q), w = P0 layout [small][25][big];
@@ -19,6 +20,7 @@
 //        stride 2 keeps even and odd halo columns in separate runs so that the 32 consecutive output
 //        pixels of a fragment read stay at the conflict-free 80-B stride;
 //   B  CB = 32: one tap [plane][n][32 bf16 + pad], double-buffered, prefetched one tap ahead (1 barrier/tap);
+//      CB = 32, at most 8 real weight rows (BRES): all 25 taps of those rows + one zero row resident (no barrier);
 //      CB = 8 : all 25 taps resident [plane][n][26 x 16 B + pad] (tap 25 = 0: the odd half of the last step).
 // Four waves, wave grid WM x WN, wave tile TM x TN fragments of 32 x 32, three v_mfma_f32_32x32x16_bf16 per
 // fragment pair exactly as igemm16.h.  Output tiles are TH x 16 pixels (TH = WM*TM*2).

@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 
 struct Tile16 { int bm, bn; };   // wave grid: 2 x 2, or 4 x 1 for the 32-column tiles
 
-inline Tile16 choose_tile16(long M, long N, int gz, bool km = false) {
+inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false) {
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
   long MINB = 384;
   if (const char* e = getenv("VP_TILE_BLOCKS")) MINB = atol(e);          // A/B knob
