@@ -74,8 +74,42 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
     be[j] = (MODE == 1 && ok && beta) ? beta[c + j] : 0.f;
   }
   if (c < C) {
-    for (int r = r0 + ty; r < r1; r += BN_TY) {
-      float xv[4], gv[4];
+    auto accum = [&](const float (&xv)[4], const float (&gv)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (MODE == 0) {
+          s0[j] += xv[j];
+          s1[j] += xv[j] * xv[j];
+        } else {
+          const float xh = (xv[j] - mu[j]) * rs[j];
+          const float g = gv[j] * act_grad_pre(ga[j] * xh + be[j], act, slope);
+          s0[j] += g;
+          s1[j] += g * xh;
+        }
+      }
+    };
+    int r = r0 + ty;
+    if (vec) {
+      // four rows per trip: 4 (MODE 0) or 8 (MODE 1) independent 16-B loads in flight; the sums are still taken in
+      // row order, so the result does not depend on the unrolling
+      for (; r + 3 * BN_TY < r1; r += 4 * BN_TY) {
+        vp_f32x4 tx4[4], td4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t off = (size_t)(r + u * BN_TY) * C + c;
+          tx4[u] = *reinterpret_cast<const vp_f32x4*>(x + off);
+          if (MODE == 1) td4[u] = *reinterpret_cast<const vp_f32x4*>(dy + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float xv[4] = {tx4[u][0], tx4[u][1], tx4[u][2], tx4[u][3]}, gv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (MODE == 1) { gv[0] = td4[u][0]; gv[1] = td4[u][1]; gv[2] = td4[u][2]; gv[3] = td4[u][3]; }
+          accum(xv, gv);
+        }
+      }
+    }
+    for (; r < r1; r += BN_TY) {
+      float xv[4], gv[4] = {0.f, 0.f, 0.f, 0.f};
       const size_t off = (size_t)r * C + c;
       if (vec) {
         vp_f32x4 t = *reinterpret_cast<const vp_f32x4*>(x + off);
@@ -91,18 +125,7 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
           if (MODE == 1) gv[j] = (c + j < C) ? dy[off + j] : 0.f;
         }
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (MODE == 0) {
-          s0[j] += xv[j];
-          s1[j] += xv[j] * xv[j];
-        } else {
-          const float xh = (xv[j] - mu[j]) * rs[j];
-          const float g = gv[j] * act_grad_pre(ga[j] * xh + be[j], act, slope);
-          s0[j] += g;
-          s1[j] += g * xh;
-        }
-      }
+      accum(xv, gv);
     }
   }
 #pragma unroll
@@ -285,7 +308,24 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(R, r0 + rows_per_chunk);
   const size_t n = (size_t)R * C;
-  for (int r = r0 + ty; r < r1; r += BN_TY) {
+  // four rows per trip: four independent 16-B loads in flight before the first use (one load per trip left the
+  // small layers at 2-3 TB/s)
+  int r = r0 + ty;
+  for (; r + 3 * BN_TY < r1; r += 4 * BN_TY) {
+    vp_f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vp_f32x4*>(x + (size_t)(r + u * BN_TY) * C + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t off = (size_t)(r + u * BN_TY) * C + c;
+      vp_f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = act_apply(v[u][j] * sc[j] + sf[j], act, slope);
+      if (y) *reinterpret_cast<vp_f32x4*>(y + off) = o;
+      if (y_split) store_split4(y_split, n, off, o[0], o[1], o[2], o[3]);
+    }
+  }
+  for (; r < r1; r += BN_TY) {
     const size_t off = (size_t)r * C + c;
     const vp_f32x4 v = *reinterpret_cast<const vp_f32x4*>(x + off);
     vp_f32x4 o;
@@ -315,10 +355,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(R, r0 + rows_per_chunk);
   const size_t n = (size_t)R * C;
-  for (int r = r0 + ty; r < r1; r += BN_TY) {
-    const size_t off = (size_t)r * C + c;
-    const vp_f32x4 xv = *reinterpret_cast<const vp_f32x4*>(x + off);
-    const vp_f32x4 dv = *reinterpret_cast<const vp_f32x4*>(dy + off);
+  auto emit = [&](size_t off, const vp_f32x4& xv, const vp_f32x4& dv) {
     vp_f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -328,6 +365,22 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
     }
     if (dx) *reinterpret_cast<vp_f32x4*>(dx + off) = o;
     if (dx_split) store_split4(dx_split, n, off, o[0], o[1], o[2], o[3]);
+  };
+  int r = r0 + ty;
+  for (; r + 3 * BN_TY < r1; r += 4 * BN_TY) {          // eight independent 16-B loads in flight
+    vp_f32x4 xv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t off = (size_t)(r + u * BN_TY) * C + c;
+      xv[u] = *reinterpret_cast<const vp_f32x4*>(x + off);
+      dv[u] = *reinterpret_cast<const vp_f32x4*>(dy + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) emit((size_t)(r + u * BN_TY) * C + c, xv[u], dv[u]);
+  }
+  for (; r < r1; r += BN_TY) {
+    const size_t off = (size_t)r * C + c;
+    emit(off, *reinterpret_cast<const vp_f32x4*>(x + off), *reinterpret_cast<const vp_f32x4*>(dy + off));
   }
 }
 
@@ -335,9 +388,13 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
 inline BnGrid bn_apply_grid(int R, int C) {
   BnGrid g;
   g.chunks_c = (C + BN_CH - 1) / BN_CH;
-  int want = 4096 / g.chunks_c;
+  int total = 4096;
+  if (const char* e = getenv("VP_BN_APPLY_BLOCKS")) total = atoi(e);    // A/B knob
+  int rows_min = 4;                                                     // trips of 16 rows per workgroup, at least
+  if (const char* e = getenv("VP_BN_APPLY_TRIPS")) rows_min = atoi(e);
+  int want = total / g.chunks_c;
   if (want < 1) want = 1;
-  int maxr = (R + BN_TY - 1) / BN_TY;
+  int maxr = (R + BN_TY * rows_min - 1) / (BN_TY * rows_min);
   g.chunks_r = want < maxr ? want : maxr;
   if (g.chunks_r < 1) g.chunks_r = 1;
   g.rows_per_chunk = (R + g.chunks_r - 1) / g.chunks_r;
