@@ -107,10 +107,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("VP_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the multi-rank path on one GPU
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     import vae_play_amd as V
     from vae_play_amd import engine, optim, parallel
