@@ -11,7 +11,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvaeplay_hip.so")
+LIB_PATH = os.environ.get("VAEPLAY_HIP_LIB", os.path.join(_HERE, "libvaeplay_hip.so"))   # override: A/B of two builds
 
 P = c_void_p  # device pointers / stream
 
