@@ -144,3 +144,33 @@ def test_autograd_modules_in_bf16x3_mode_match_golden():
         l2 = g[f"grad_l2/{n}"][0]
         got = p.grad.double().pow(2).sum().sqrt().item()
         assert abs(got - l2) <= 5e-3 * l2 + 1e-12, f"{n}: {got} vs {l2}"
+
+
+def test_concurrent_schedule_is_bit_identical_to_the_serial_one(monkeypatch):
+    """The side-stream schedule (weight gradients, weight re-pack, bias column sums overlapping the main chain) changes no
+    arithmetic: from the same state, 25 steps under VP_SIDE_WGRAD=1 and under VP_SIDE_WGRAD=0 must leave bit-identical
+    parameters, optimiser moments and BatchNorm buffers.  A missing event wait (a race on the ping-ponged gradient
+    buffers or the shared weight-gradient workspace) shows up here as a difference."""
+    import vae_play_amd as V
+    from vae_play_amd import optim
+    from vae_play_amd.engine import FusedVAEStep
+    states = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VP_SIDE_WGRAD", mode)
+        torch.manual_seed(3)
+        vae = V.VAE(64, 32, 3).cuda()
+        opt = optim.Adam(vae.parameters(), lr=1e-4)
+        st = FusedVAEStep(vae, opt, 16, 64, 3)
+        assert (st._side_ctx() is not None) == (mode == "1")
+        g = torch.Generator().manual_seed(4)
+        for i in range(25):
+            x = torch.rand(16, 3, 64, 64, generator=g).cuda()
+            eps = torch.randn(16, 32, generator=g).cuda()
+            st.step(x, eps)
+        torch.cuda.synchronize()
+        states.append((opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                       [b.clone() for b in vae.buffers() if b.dtype.is_floating_point]))
+    a, b = states
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for u, v in zip(a[3], b[3]):
+        assert torch.equal(u, v)
