@@ -462,11 +462,17 @@ inline int wgrad_nsplit(const ConvGeom& g) {
   // smaller slabs for the reduction kernel
   long target = 384;
   if (const char* e = getenv("VP_WGRAD_BLOCKS")) target = atol(e);      // A/B knob
+  // tiny weights (<= 1024 entries per tap: the 1-8-channel predictor convolutions of the segmentation heads, run over
+  // 256x256 images): one 32-row tile per tap does all the work of a million-pixel contraction, so split far deeper
+  // (the slabs stay small); measured on tools/bench_be_heads.py
+  const bool tiny = (long)g.Cs * g.Cb <= 1024;
+  if (tiny) target = 4096;
   long want = (target + tiles - 1) / tiles;
   long maxs = (K + 511) / 512;  // keep >= 16 K-tiles of 32 per split
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
+  const long cap = tiny ? 512 : 64;
+  if (s > cap) s = cap;
   return (int)s;
 }
 
