@@ -150,6 +150,13 @@ int vp_bn_act_bwd_f32(const float* x, const float* dy, const float* mean, const 
                       const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
                       int R, int C, int act, float slope, int batch_stats,
                       void* ws, size_t ws_bytes, vp_stream stream);
+/* nn.InstanceNorm2d(affine=False, eps) + activation over B images of [R = H*W][C] NHWC (models/blocks.py:22): per-(image,
+ * channel) statistics; mean / rstd [B][C] are outputs of the forward and inputs of the backward. */
+size_t vp_instnorm_workspace_bytes(int B, int R, int C);
+int vp_instnorm_act_fwd_f32(const float* x, float* y, float* mean, float* rstd, int B, int R, int C, float eps, int act,
+                            float slope, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_instnorm_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, float* dx, int B, int R, int C,
+                            int act, float slope, void* ws, size_t ws_bytes, vp_stream stream);
 /* plain activation (conv + bias + act blocks of models/blocks.py:24-30 with bn=None) */
 int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream);
 /* dx = dy * act'(.) evaluated from the OUTPUT y (relu/lrelu/tanh/sigmoid); dx may alias dy */

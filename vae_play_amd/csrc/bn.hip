@@ -56,7 +56,10 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ part, int R, int C, int rows_per_chunk,
-                                                         int act, float slope) {
+                                                         int act, float slope, size_t bxs = 0, size_t bps = 0) {
+  // blockIdx.z = image index of a batched (InstanceNorm) call: bxs elements per image, bps partial floats per image
+  x += blockIdx.z * bxs; part += blockIdx.z * bps;
+  if (MODE == 1) { dy += blockIdx.z * bxs; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C; }
   __shared__ float sh[2][BN_TY][BN_CH + 4];
   const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
   const int c = blockIdx.y * BN_CH + tx * 4;
@@ -172,7 +175,8 @@ __device__ __forceinline__ void bn_final_reduce(const float* __restrict__ part, 
 
 __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __restrict__ part, int nchunk, int R, int C, float eps,
                                                              float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                                             float* __restrict__ rm, float* __restrict__ rv) {
+                                                             float* __restrict__ rm, float* __restrict__ rv, size_t bps = 0) {
+  part += blockIdx.z * bps; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
   const int c = blockIdx.x * FIN_C + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   double s, q;
   bn_final_reduce(part, nchunk, C, c, lane, s, q);
@@ -191,7 +195,8 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __rest
 
 __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* __restrict__ part, int nchunk, int C,
                                                            float* __restrict__ sum_g, float* __restrict__ sum_gx,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, size_t bps = 0) {
+  part += blockIdx.z * bps; sum_g += blockIdx.z * (size_t)C; sum_gx += blockIdx.z * (size_t)C;
   const int c = blockIdx.x * FIN_C + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   double s, q;
   bn_final_reduce(part, nchunk, C, c, lane, s, q);
@@ -206,7 +211,10 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* __restri
 __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, size_t n,
-                                                         int C, int act, float slope, u16_t* __restrict__ y_split) {
+                                                         int C, int act, float slope, u16_t* __restrict__ y_split,
+                                                         size_t bxs = 0) {
+  x += blockIdx.z * bxs; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
+  if (y) y += blockIdx.z * bxs;
   const bool vec = (C % 4 == 0);
   if (vec) {
     const size_t n4 = n / 4;
@@ -240,7 +248,10 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
                                                          float* dx, size_t n, int C, float invR, int act,
-                                                         float slope, u16_t* __restrict__ dx_split) {
+                                                         float slope, u16_t* __restrict__ dx_split, size_t bxs = 0) {
+  x += blockIdx.z * bxs; dy += blockIdx.z * bxs; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
+  sum_g += blockIdx.z * (size_t)C; sum_gx += blockIdx.z * (size_t)C;
+  if (dx) dx += blockIdx.z * bxs;
   const bool vec = (C % 4 == 0);
   const size_t cnt = vec ? n / 4 : n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
@@ -295,7 +306,9 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ y,
                                                                u16_t* __restrict__ y_split, int R, int C, int rows_per_chunk,
-                                                               int act, float slope) {
+                                                               int act, float slope, size_t bxs = 0) {
+  x += blockIdx.z * bxs; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
+  if (y) y += blockIdx.z * bxs;
   const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
   const int c = blockIdx.y * BN_CH + tx * 4;
   if (c >= C) return;
@@ -341,7 +354,11 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
                                                                float* dx, u16_t* __restrict__ dx_split, int R, int C,
-                                                               int rows_per_chunk, float invR, int act, float slope) {
+                                                               int rows_per_chunk, float invR, int act, float slope,
+                                                               size_t bxs = 0) {
+  x += blockIdx.z * bxs; dy += blockIdx.z * bxs; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
+  sum_g += blockIdx.z * (size_t)C; sum_gx += blockIdx.z * (size_t)C;
+  if (dx) dx += blockIdx.z * bxs;
   const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
   const int c = blockIdx.y * BN_CH + tx * 4;
   if (c >= C) return;
@@ -502,6 +519,69 @@ int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, 
                             const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta, int R, int C, int act,
                             float slope, int batch_stats, void* ws, size_t ws_bytes, vp_stream stream) {
   return bn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, dx, dx_split, dgamma, dbeta, R, C, act, slope, batch_stats, ws, ws_bytes, stream);
+}
+
+// ---- nn.InstanceNorm2d(affine=False) + activation: the same kernels with blockIdx.z = image (models/blocks.py:22) --------
+size_t vp_instnorm_workspace_bytes(int B, int R, int C) { return (size_t)B * bn_ws_floats(R, C) * sizeof(float); }
+
+int vp_instnorm_act_fwd_f32(const float* x, float* y, float* mean, float* rstd, int B, int R, int C, float eps, int act,
+                            float slope, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(x && y && mean && rstd && ws && B > 0 && R > 0 && C > 0, "vp_instnorm_act_fwd_f32: bad arguments");
+  if (ws_bytes < vp_instnorm_workspace_bytes(B, R, C)) return fail(VP_ERR_WORKSPACE, "vp_instnorm_act_fwd_f32: workspace too small");
+  const BnGrid g = bn_grid(R, C);
+  const size_t bxs = (size_t)R * C, bps = (size_t)2 * g.chunks_r * C;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)ws;
+  hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(g.chunks_r, g.chunks_c, B), dim3(256), 0, s, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, R, C,
+                     g.rows_per_chunk, 0, 0.f, bxs, bps);
+  int rc = check_launch("vp_instnorm_act_fwd_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_C - 1) / FIN_C, 1, B), dim3(256), 0, s, (const float*)part, g.chunks_r, R, C,
+                     eps, 0.f, mean, rstd, (float*)nullptr, (float*)nullptr, bps);
+  rc = check_launch("vp_instnorm_act_fwd_f32(final)");
+  if (rc) return rc;
+  if (C % 4 == 0) {
+    const BnGrid ga = bn_apply_grid(R, C);
+    hipLaunchKernelGGL(bn_act_fwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c, B), dim3(256), 0, s, x, (const float*)mean,
+                       (const float*)rstd, (const float*)nullptr, (const float*)nullptr, y, (u16_t*)nullptr, R, C, ga.rows_per_chunk,
+                       act, slope, bxs);
+  } else {
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(bxs / 4 + 1, 256), 1, B), dim3(256), 0, s, x, (const float*)mean,
+                       (const float*)rstd, (const float*)nullptr, (const float*)nullptr, y, bxs, C, act, slope, (u16_t*)nullptr, bxs);
+  }
+  return check_launch("vp_instnorm_act_fwd_f32(apply)");
+}
+
+int vp_instnorm_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, float* dx, int B, int R, int C,
+                            int act, float slope, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(x && dy && mean && rstd && dx && ws && B > 0 && R > 0 && C > 0, "vp_instnorm_act_bwd_f32: bad arguments");
+  if (ws_bytes < vp_instnorm_workspace_bytes(B, R, C)) return fail(VP_ERR_WORKSPACE, "vp_instnorm_act_bwd_f32: workspace too small");
+  const BnGrid g = bn_grid(R, C);
+  const size_t bxs = (size_t)R * C, bps = (size_t)2 * g.chunks_r * C;
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)ws;
+  float* sum_g = part + (size_t)B * bps;          // [B][C], then sum_gx [B][C]
+  float* sum_gx = sum_g + (size_t)B * C;
+  hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(g.chunks_r, g.chunks_c, B), dim3(256), 0, s, x, dy, mean, rstd, (const float*)nullptr,
+                     (const float*)nullptr, part, R, C, g.rows_per_chunk, act, slope, bxs, bps);
+  int rc = check_launch("vp_instnorm_act_bwd_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FIN_C - 1) / FIN_C, 1, B), dim3(256), 0, s, (const float*)part, g.chunks_r, C, sum_g,
+                     sum_gx, (float*)nullptr, (float*)nullptr, bps);
+  rc = check_launch("vp_instnorm_act_bwd_f32(final)");
+  if (rc) return rc;
+  const float invR = 1.f / (float)R;
+  if (C % 4 == 0) {
+    const BnGrid ga = bn_apply_grid(R, C);
+    hipLaunchKernelGGL(bn_act_bwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c, B), dim3(256), 0, s, x, dy, mean, rstd,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)sum_g, (const float*)sum_gx, dx, (u16_t*)nullptr, R, C,
+                       ga.rows_per_chunk, invR, act, slope, bxs);
+  } else {
+    hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(grid_for(bxs / 4 + 1, 256), 1, B), dim3(256), 0, s, x, dy, mean, rstd, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)sum_g, (const float*)sum_gx, dx, bxs, C, invR, act, slope, (u16_t*)nullptr, bxs);
+  }
+  return check_launch("vp_instnorm_act_bwd_f32(apply)");
 }
 
 int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream) {

@@ -262,34 +262,21 @@ class _Act(Function):
 
 
 class _InstanceNormAct(Function):
-    """nn.InstanceNorm2d (affine=False, no running stats, eps 1e-5) + activation: per-(image, channel) statistics.
-    Runs the BatchNorm kernels on each image's [H*W][C] NHWC slice."""
+    """nn.InstanceNorm2d (affine=False, no running stats, eps 1e-5) + activation: per-(image, channel) statistics, one
+    batched launch sequence (the BatchNorm kernels with blockIdx.z = image)."""
 
     @staticmethod
     def forward(ctx, x, eps: float, act: int, slope: float):
         x = _cl(x)
-        B = x.shape[0]
-        y = torch.empty_like(x)
-        means, rstds = [], []
-        for b in range(B):
-            xb = x[b:b + 1]
-            mean, rstd = ops.bn_stats(xb, eps, 0.0)
-            yb = ops.bn_act_fwd(xb, mean, rstd, None, None, act, slope)
-            y[b:b + 1].copy_(yb)
-            means.append(mean); rstds.append(rstd)
+        y, mean, rstd = ops.instnorm_act_fwd(x, eps, act, slope)
         ctx.act, ctx.slope = act, slope
-        ctx.save_for_backward(x, torch.stack(means), torch.stack(rstds))
+        ctx.save_for_backward(x, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, means, rstds = ctx.saved_tensors
-        dy = _cl(dy)
-        dx = torch.empty_like(x)
-        for b in range(x.shape[0]):
-            dxb, _, _ = ops.bn_act_bwd(x[b:b + 1], dy[b:b + 1], means[b], rstds[b], None, None, ctx.act, ctx.slope, True, False)
-            dx[b:b + 1].copy_(dxb)
-        return dx, None, None, None
+        x, mean, rstd = ctx.saved_tensors
+        return ops.instnorm_act_bwd(x, _cl(dy), mean, rstd, ctx.act, ctx.slope), None, None, None
 
 
 class _Upsample2x(Function):

@@ -213,6 +213,26 @@ def bn_act_bwd(x, dy, mean, rstd, gamma, beta, act: int, slope: float, batch_sta
     return dx, dgamma, dbeta
 
 
+def instnorm_act_fwd(x, eps: float, act: int, slope: float = 0.0):
+    """x: (B, C, H, W) channels_last -> (y, mean[B][C], rstd[B][C])."""
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    ws = _ws(_lib.load().vp_instnorm_workspace_bytes(B, H * W, C), x)
+    _lib.call("vp_instnorm_act_fwd_f32", _p(x), _p(y), _p(mean), _p(rstd), B, H * W, C, eps, act, slope, _p(ws), ws.numel() * 4, _stream())
+    return y, mean, rstd
+
+
+def instnorm_act_bwd(x, dy, mean, rstd, act: int, slope: float = 0.0):
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    ws = _ws(_lib.load().vp_instnorm_workspace_bytes(B, H * W, C), x)
+    _lib.call("vp_instnorm_act_bwd_f32", _p(x), _p(dy), _p(mean), _p(rstd), _p(dx), B, H * W, C, act, slope, _p(ws), ws.numel() * 4,
+              _stream())
+    return dx
+
+
 def act_fwd(x, act: int, slope: float = 0.0):
     y = torch.empty_like(x)
     _lib.call("vp_act_fwd_f32", _p(x), _p(y), x.numel(), act, float(slope), _stream())
