@@ -31,6 +31,18 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __rest
   }
 }
 
+// Wide form (C >= 64: dense-layer bias gradients, R = batch): one thread per channel, coalesced across channels, rows in a
+// loop -- the row-lane form above walks the channels one wavefront at a time (40 us for C = 256, R = 8).
+__global__ void __launch_bounds__(256) colsum_wide_kernel(const float* __restrict__ x, float* __restrict__ partial, int R, int C,
+                                                          int rows_per_chunk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += x[(size_t)r * C + c];
+  partial[(size_t)blockIdx.y * C + c] = s;
+}
+
 // one wavefront per channel: the 64 lanes split the chunk partials, fp64 wave reduction
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int nchunk) {
   const int c = blockIdx.x;
@@ -95,7 +107,10 @@ int vp_colsum_f32(const float* x, float* out, int R, int C, void* ws, size_t ws_
   if (ws_bytes < (size_t)nchunk * C * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_colsum_f32: workspace too small");
   const int rpc = (R + nchunk - 1) / nchunk;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk), dim3(64, 4), 0, s, x, (float*)ws, R, C, rpc);
+  if (C >= 64)
+    hipLaunchKernelGGL(colsum_wide_kernel, dim3((C + 255) / 256, nchunk), dim3(256), 0, s, x, (float*)ws, R, C, rpc);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk), dim3(64, 4), 0, s, x, (float*)ws, R, C, rpc);
   int rc = check_launch("vp_colsum_f32(partial)");
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, s, (const float*)ws, out, C, nchunk);
