@@ -78,6 +78,17 @@ int vp_conv_wgrad_f32(const float* big, const float* small, float* dw_ref,
                       int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride,
                       void* ws, size_t ws_bytes, vp_stream stream);
 
+/* k x k (k = 1, 3, 5; padding (k-1)/2; explicit big size Hb x Wb as for vp_conv_gather_f32) forms of the three split-bf16
+ * families, for the models/blocks.py vocabulary; weights packed by vp_pack_w_split: p0 = [Csmall][k*k][Cbig],
+ * p1 = [Cbig][k*k][Csmall], both as bf16 hi/lo planes. */
+int vp_pack_w_split(const float* w_ref, void* p0_split, void* p1_split, int Csmall, int Cbig, int ks, vp_stream stream);
+int vp_conv_gather_bf16x3(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws,
+                          int Hb, int Wb, int Cbig, int Csmall, int ks, int stride, int act, vp_stream stream);
+int vp_conv_scatter_bf16x3(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb,
+                           int Csmall, int Cbig, int ks, int stride, vp_stream stream);
+size_t vp_conv_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride);
+int vp_conv_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
+                         int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream);
 /* ---- split-bf16 ("bf16x3") variants of the three families ------------------------------------------
  * A "split" tensor stores an fp32 tensor of n elements as two bf16 planes in one buffer of 2*n
  * uint16: hi = bf16(x) at [0,n), lo = bf16(x - hi) at [n,2n).  The contraction issues three

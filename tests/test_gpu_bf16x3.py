@@ -80,3 +80,32 @@ def test_split_outputs_of_bn_and_transpose():
     ts = ops.empty_split(xn.numel(), xn)
     _lib.call("vp_nchw_to_nhwc_split_f32", ops._p(xn), None, ops._pv(ts), B, C, H, H, st)
     assert_close(ops.unsplit(ts), xn.permute(0, 2, 3, 1).reshape(-1), 2 ** -15, "transpose split out")
+
+
+KXK = [  # (B, Hb, Wb, Cb, Cs, ks, stride): the models/blocks.py vocabulary on the split-bf16 kernels, incl. odd sizes
+    (2, 16, 16, 16, 24, 3, 1), (2, 17, 13, 8, 16, 3, 2), (3, 12, 12, 64, 64, 3, 2), (2, 9, 9, 32, 8, 1, 1), (1, 20, 14, 16, 8, 1, 2),
+    (2, 15, 15, 8, 8, 5, 2), (4, 32, 32, 128, 64, 3, 1), (2, 7, 9, 24, 40, 5, 1),
+]
+
+
+@pytest.mark.parametrize("B,Hb,Wb,Cb,Cs,ks,stride", KXK)
+def test_bf16x3_kxk_families(B, Hb, Wb, Cb, Cs, ks, stride):
+    from vae_play_amd import ops
+    g = torch.Generator().manual_seed(B + Hb + Cb + Cs + ks)
+    pad = (ks - 1) // 2
+    big = torch.randn(B, Cb, Hb, Wb, generator=g)
+    w = torch.randn(Cs, Cb, ks, ks, generator=g) * 0.1
+    bias = torch.randn(Cs, generator=g)
+    ref = F.conv2d(big, w, bias, stride=stride, padding=pad)
+    small = torch.randn(ref.shape, generator=g)
+    big_s, small_s = ops.split_f32(nhwc(big)), ops.split_f32(nhwc(small))
+    p0, p1 = ops.pack_w_split(w.to(DEV), True, True)
+    y = ops.conv_gather_bf16x3(big_s, big.shape, p0, Cs, bias.to(DEV), ks, stride, 0)
+    assert_close(y, ref, X3_RTOL, "k x k gather bf16x3")
+    bigr = big.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(bigr, wr, None, stride=stride, padding=pad).backward(small)
+    dx = ops.conv_scatter_bf16x3(small_s, small.shape, p1, Cb, ks, stride, Hb, Wb)
+    assert_close(dx, bigr.grad, X3_RTOL, "k x k scatter bf16x3")
+    dw = ops.conv_wgrad_bf16x3(big_s, big.shape, small_s, small.shape, ks, stride)
+    assert_close(dw, wr.grad, X3_RTOL, "k x k wgrad bf16x3")

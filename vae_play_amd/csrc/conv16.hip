@@ -148,6 +148,65 @@ static bool halo_enabled() {
   return on;
 }
 
+template <class PF>
+static int gather16_t(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws, int Hb,
+                      int Wb, int Cbig, int Csmall, int ks, int stride, int act, bool plain5, vp_stream stream) {
+  PF p;
+  p.zero = vp_zero_page();
+  p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  p.big = (const u16*)big_split; p.big_plane = (size_t)B * p.g.Hb * p.g.Wb * Cbig;
+  p.w = (const u16*)w_p0_split; p.w_plane = (size_t)Csmall * Cbig * p.g.nt;
+  p.bias = bias; p.out = small_out; p.act = act;
+  p.M = B * Hs * Ws; p.N = Csmall; p.K = p.g.nt * Cbig;
+  // few output tiles and a long K (the 8x8-resolution layers: 256 workgroups = one per CU): split K in two and
+  // accumulate both halves with fp32 atomics onto a zeroed output (two addends: the sum does not depend on order)
+  const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64);
+  p.nsplit = (plain5 && !bias && act == VP_ACT_NONE && Cbig % 64 == 0 && tiles < 384 && p.K >= 4096) ? 2 : 1;
+  p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
+  if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
+  p.xcd_map = xcd_map_for(p.M, p.N, p.nsplit);
+  launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig);
+  return check_launch("vp_conv_gather_bf16x3");
+}
+
+template <class PT>
+static int scatter16_t(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb, int Csmall,
+                       int Cbig, int ks, int stride, bool plain5, vp_stream stream) {
+  PT p;
+  p.zero = vp_zero_page();
+  p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
+  p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * p.g.nt;
+  p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
+  const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64) * stride * stride;
+  p.nsplit = (plain5 && Csmall % 64 == 0 && tiles < 384 && 4 * Csmall >= 1024) ? 2 : 1;
+  if (p.nsplit == 2 &&
+      hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
+  p.xcd_map = xcd_map_for(p.M, p.N, stride * stride * p.nsplit);
+  launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
+  return check_launch("vp_conv_scatter_bf16x3");
+}
+
+template <class PW>
+static int wgrad16_t(const void* big_split, const void* small_split, float* dw_ref, const ConvGeom& g, int ns, void* ws, vp_stream stream) {
+  const int B = g.B, Hs = g.Hs, Ws = g.Ws, Cbig = g.Cb, Csmall = g.Cs;
+  PW p;
+  p.zero = vp_zero_page();
+  p.g = g;
+  p.big = (const u16*)big_split; p.big_plane = (size_t)B * g.Hb * g.Wb * Cbig;
+  p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
+  p.slab = (float*)ws; p.M = Csmall; p.N = Cbig; p.K = B * Hs * Ws;
+  p.nsplit = ns;
+  const int per = (p.K + ns - 1) / ns;
+  p.k_per_split = ((per + 31) / 32) * 32;
+  launch_igemm16(p, p.M, p.N, g.nt * ns, (hipStream_t)stream);
+  int rc = check_launch("vp_conv_wgrad_bf16x3(main)");
+  if (rc) return rc;
+  return slab_reduce_launch((const float*)ws, dw_ref, Csmall, Cbig, ns, (hipStream_t)stream, g.nt);
+}
+
 extern "C" {
 
 int vp_split_f32(const float* x, void* out_split, size_t n, vp_stream stream) {
@@ -194,56 +253,62 @@ int vp_pack_w5_p1_split_padded(const float* w_ref, void* p1_split, int Csmall, i
   return pack_w5_launch<true>(w_ref, nullptr, p1_split, Csmall, Cbig, (hipStream_t)stream, "vp_pack_w5_p1_split_padded", Csmall_pad);
 }
 
-int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs,
-                           int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream) {
-  VP_REQUIRE(big_split && w_p0_split && small_out, "vp_conv5_gather_bf16x3: null pointer");
-  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Cbig % 8 == 0, "vp_conv5_gather_bf16x3: Cbig must be a multiple of 8");
-  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_gather_bf16x3: stride must be 1 or 2");
-  VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv5_gather_bf16x3: epilogue supports none|sigmoid");
-  if (halo_enabled())
+static int gather16(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws, int Hb,
+                    int Wb, int Cbig, int Csmall, int ks, int stride, int act, vp_stream stream) {
+  VP_REQUIRE(big_split && w_p0_split && small_out, "vp_conv_gather_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Cbig % 8 == 0, "vp_conv_gather_bf16x3: Cbig must be a multiple of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv_gather_bf16x3: stride must be 1 or 2");
+  VP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "vp_conv_gather_bf16x3: kernel size must be 1, 3 or 5");
+  VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv_gather_bf16x3: epilogue supports none|sigmoid");
+  const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
+  if (plain5 && halo_enabled())
     if (const int kind = halo_gather_kind(B, Hs, Ws, Cbig, Csmall, stride))
       return halo_gather_launch(kind, big_split, w_p0_split, bias, small_out, B, Hs, Ws, Cbig, Csmall, stride, act, (hipStream_t)stream);
-  ProbF16 p;
-  p.zero = vp_zero_page();
-  p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
-  p.big = (const u16*)big_split; p.big_plane = (size_t)B * p.g.Hb * p.g.Wb * Cbig;
-  p.w = (const u16*)w_p0_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
-  p.bias = bias; p.out = small_out; p.act = act;
-  p.M = B * Hs * Ws; p.N = Csmall; p.K = kTaps * Cbig;
-  // few output tiles and a long K (the 8x8-resolution layers: 256 workgroups = one per CU): split K in two and
-  // accumulate both halves with fp32 atomics onto a zeroed output (two addends: the sum does not depend on order)
-  const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64);
-  p.nsplit = (!bias && act == VP_ACT_NONE && Cbig % 64 == 0 && tiles < 384 && p.K >= 4096) ? 2 : 1;
-  p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
-  if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
-    return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
-  p.xcd_map = xcd_map_for(p.M, p.N, p.nsplit);
-  launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig);
-  return check_launch("vp_conv5_gather_bf16x3");
+  if (!plain5) return gather16_t<ProbF16K>(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, act, false, stream);
+  return gather16_t<ProbF16>(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, act, true, stream);
 }
+
+
+int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs,
+                           int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream) {
+  return gather16(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride, act, stream);
+}
+
+int vp_conv_gather_bf16x3(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws,
+                          int Hb, int Wb, int Cbig, int Csmall, int ks, int stride, int act, vp_stream stream) {
+  return gather16(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, act, stream);
+}
+
+static int scatter16(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb, int Csmall,
+                     int Cbig, int ks, int stride, vp_stream stream) {
+  VP_REQUIRE(small_split && w_p1_split && big_out, "vp_conv_scatter_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Csmall % 8 == 0, "vp_conv_scatter_bf16x3: Csmall must be a multiple of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv_scatter_bf16x3: stride must be 1 or 2");
+  VP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "vp_conv_scatter_bf16x3: kernel size must be 1, 3 or 5");
+  const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
+  if (plain5 && halo_enabled())
+    if (const int kind = halo_scatter_kind(B, Hs, Ws, Csmall, Cbig, stride))
+      return halo_scatter_launch(kind, small_split, w_p1_split, big_out, B, Hs, Ws, Csmall, Cbig, (hipStream_t)stream);
+  if (!plain5) return scatter16_t<ProbT16K>(small_split, w_p1_split, big_out, B, Hs, Ws, Hb, Wb, Csmall, Cbig, ks, stride, false, stream);
+  return scatter16_t<ProbT16>(small_split, w_p1_split, big_out, B, Hs, Ws, Hb, Wb, Csmall, Cbig, ks, stride, true, stream);
+}
+
 
 int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Csmall,
                             int Cbig, int stride, vp_stream stream) {
-  VP_REQUIRE(small_split && w_p1_split && big_out, "vp_conv5_scatter_bf16x3: null pointer");
-  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Csmall % 8 == 0, "vp_conv5_scatter_bf16x3: Csmall must be a multiple of 8");
-  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_scatter_bf16x3: stride must be 1 or 2");
-  if (halo_enabled())
-    if (const int kind = halo_scatter_kind(B, Hs, Ws, Csmall, Cbig, stride))
-      return halo_scatter_launch(kind, small_split, w_p1_split, big_out, B, Hs, Ws, Csmall, Cbig, (hipStream_t)stream);
-  ProbT16 p;
-  p.zero = vp_zero_page();
-  p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
-  p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
-  p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * kTaps;
-  p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
-  const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64) * stride * stride;
-  p.nsplit = (Csmall % 64 == 0 && tiles < 384 && 4 * Csmall >= 1024) ? 2 : 1;
-  if (p.nsplit == 2 &&
-      hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
-    return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
-  p.xcd_map = xcd_map_for(p.M, p.N, stride * stride * p.nsplit);
-  launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
-  return check_launch("vp_conv5_scatter_bf16x3");
+  return scatter16(small_split, w_p1_split, big_out, B, Hs, Ws, Hs * stride, Ws * stride, Csmall, Cbig, 5, stride, stream);
+}
+
+int vp_conv_scatter_bf16x3(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb,
+                           int Csmall, int Cbig, int ks, int stride, vp_stream stream) {
+  return scatter16(small_split, w_p1_split, big_out, B, Hs, Ws, Hb, Wb, Csmall, Cbig, ks, stride, stream);
+}
+
+int vp_pack_w_split(const float* w_ref, void* p0_split, void* p1_split, int Csmall, int Cbig, int ks, vp_stream stream) {
+  VP_REQUIRE(w_ref && (p0_split || p1_split) && Csmall > 0 && Cbig > 0, "vp_pack_w_split: bad arguments");
+  VP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "vp_pack_w_split: kernel size must be 1, 3 or 5");
+  VP_REQUIRE(Csmall <= 65535 && Cbig <= 65535, "vp_pack_w_split: channel count too large");
+  return pack_w5_launch<true>(w_ref, p0_split, p1_split, Csmall, Cbig, (hipStream_t)stream, "vp_pack_w_split", 0, ks * ks);
 }
 
 size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
@@ -251,27 +316,37 @@ size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, in
   return wgrad_slab_floats(g, wgrad_nsplit(g)) * sizeof(float);
 }
 
+size_t vp_conv_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride) {
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  return wgrad_slab_floats(g, wgrad_nsplit(g)) * sizeof(float);
+}
+
+static int wgrad16(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
+                   int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream);
+
 int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,
                           int Csmall, int stride, void* ws, size_t ws_bytes, vp_stream stream) {
-  VP_REQUIRE(big_split && small_split && dw_ref && ws, "vp_conv5_wgrad_bf16x3: null pointer");
-  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig % 8 == 0 && Csmall % 8 == 0 && Cbig > 0 && Csmall > 0,
-             "vp_conv5_wgrad_bf16x3: channel counts must be multiples of 8");
-  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv5_wgrad_bf16x3: stride must be 1 or 2");
-  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
-  const int ns = wgrad_nsplit(g);
-  if (ws_bytes < wgrad_slab_floats(g, ns) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_wgrad_bf16x3: workspace too small");
-  ProbW16 p;
-  p.zero = vp_zero_page();
-  p.g = g;
-  p.big = (const u16*)big_split; p.big_plane = (size_t)B * g.Hb * g.Wb * Cbig;
-  p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
-  p.slab = (float*)ws; p.M = Csmall; p.N = Cbig; p.K = B * Hs * Ws;
-  p.nsplit = ns;
-  const int per = (p.K + ns - 1) / ns;
-  p.k_per_split = ((per + 31) / 32) * 32;
-  launch_igemm16(p, p.M, p.N, kTaps * ns, (hipStream_t)stream);
-  int rc = check_launch("vp_conv5_wgrad_bf16x3(main)");
-  if (rc) return rc;
-  return slab_reduce_launch((const float*)ws, dw_ref, Csmall, Cbig, ns, (hipStream_t)stream);
+  return wgrad16(big_split, small_split, dw_ref, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride, ws, ws_bytes, stream);
 }
+
+int vp_conv_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
+                         int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream) {
+  return wgrad16(big_split, small_split, dw_ref, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, ws, ws_bytes, stream);
+}
+
+static int wgrad16(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
+                   int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(big_split && small_split && dw_ref && ws, "vp_conv_wgrad_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig % 8 == 0 && Csmall % 8 == 0 && Cbig > 0 && Csmall > 0,
+             "vp_conv_wgrad_bf16x3: channel counts must be multiples of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv_wgrad_bf16x3: stride must be 1 or 2");
+  VP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "vp_conv_wgrad_bf16x3: kernel size must be 1, 3 or 5");
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  const int ns = wgrad_nsplit(g);
+  if (ws_bytes < wgrad_slab_floats(g, ns) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv_wgrad_bf16x3: workspace too small");
+  const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
+  if (!plain5) return wgrad16_t<ProbW16K>(big_split, small_split, dw_ref, g, ns, ws, stream);
+  return wgrad16_t<ProbW16>(big_split, small_split, dw_ref, g, ns, ws, stream);
+}
+
 }

@@ -61,7 +61,13 @@ struct Lds16 {
 
 // ---- problem descriptors (vector path only: channel counts are multiples of 8) -----------------
 // F family on split planes: A(m=(b,hs,ws), k=(tap,c)) = big[...]; B(n, k) = wp0[n][tap][c]
-struct ProbF16 {
+template <bool K5>
+struct ProbF16T {
+  // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
+  // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
+  VP_HD int ks() const { return K5 ? 5 : g.ks; }
+  VP_HD int pad() const { return K5 ? 2 : g.pad; }
+  VP_HD int nt() const { return K5 ? 25 : g.nt; }
   static constexpr bool A_KM = false, B_KM = false;
   const u16* big; size_t big_plane;     // hi plane at big, lo plane at big + big_plane (elements)
   const u16* w; size_t w_plane;         // packed P0 planes [Cs][25][Cb]
@@ -81,7 +87,7 @@ struct ProbF16 {
     ARow r; r.valid = m < M; int mm = r.valid ? m : 0;
     int b = (int)g.dHW.div((uint32_t)mm); int rem = mm - b * (g.Hs * g.Ws);
     int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
-    r.pix_base = b * g.Hb * g.Wb; r.h0 = g.stride * hs - 2; r.w0 = g.stride * ws - 2;
+    r.pix_base = b * g.Hb * g.Wb; r.h0 = g.stride * hs - pad(); r.w0 = g.stride * ws - pad();
     return r;
   }
   // Every gather is branch-free: out-of-range chunks read the zero page, so a K-tile's loads are issued
@@ -93,7 +99,7 @@ struct ProbF16 {
     const int kt = FAST ? k0 : k0 + k8;
     const int tap = (int)g.dCb.div((uint32_t)kt);
     const int c = k0 + k8 - tap * g.Cb;
-    const int rr = div_small(tap, 5), qq = tap - rr * 5;
+    const int rr = div_small(tap, ks()), qq = tap - rr * ks();
     const int h = r.h0 + rr, w_ = r.w0 + qq;
     const bool ok = r.valid && kt < z.k_end && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
     return ld16(ok ? big + plane * big_plane + (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c : reinterpret_cast<const u16*>(zero));
@@ -119,8 +125,8 @@ struct ProbF16 {
   template <int SH = 6>
   VP_HD bool a_base(const ARow& r, int k0, const ZCtx& z, size_t& off) const {
     int tap, c0;
-    fast_tile<SH>(k0, kTaps, tap, c0);
-    const int rr = div_small(tap, 5), qq = tap - rr * 5;
+    fast_tile<SH>(k0, nt(), tap, c0);
+    const int rr = div_small(tap, ks()), qq = tap - rr * ks();
     const int h = r.h0 + rr, w_ = r.w0 + qq;
     off = (size_t)(r.pix_base + h * g.Wb + w_) * g.Cb + c0;
     return r.valid && k0 < z.k_end && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
@@ -128,7 +134,7 @@ struct ProbF16 {
   template <int SH = 6>
   VP_HD bool b_base(const BRow& r, int k0, const ZCtx& z, size_t& off) const {
     int tap, c0;
-    fast_tile<SH>(k0, kTaps, tap, c0);
+    fast_tile<SH>(k0, nt(), tap, c0);
     off = (size_t)r.off + tap * g.Cb + c0;
     return r.valid && k0 < z.k_end;
   }
@@ -146,22 +152,32 @@ struct ProbF16 {
     out[(size_t)m * N + n] = v;
   }
 };
+using ProbF16 = ProbF16T<true>;
+using ProbF16K = ProbF16T<false>;
 
 // T family on split planes (phase-decomposed transposed conv)
-struct ProbT16 {
+template <bool K5>
+struct ProbT16T {
+  // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
+  // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
+  VP_HD int ks() const { return K5 ? 5 : g.ks; }
+  VP_HD int pad() const { return K5 ? 2 : g.pad; }
+  VP_HD int nt() const { return K5 ? 25 : g.nt; }
   static constexpr bool A_KM = false, B_KM = false;
   const u16* small; size_t small_plane;
   const u16* w; size_t w_plane;          // packed P1 planes [Cb][25][Cs]
   float* out; const void* zero; ConvGeom g; int M, N;
   int nsplit;                // 1, or 2: z = phase*2 + half, halves atomically added onto a zeroed output
   int xcd_map;
-  struct ZCtx { int k_begin, k_end, ph, pw, th, tw; };
+  struct ZCtx { int k_begin, k_end, ph, pw, th, tw, r0h, r0w, bh, bw; };   // phase geometry as in problems.h ProbT
   struct ARow { int pix_base, q, p, valid; };
   struct BRow { int off, valid; };
   VP_HD void z_setup(int zi, ZCtx& z) const {
     const int phase = zi / nsplit, half = zi - phase * nsplit;
     int s = g.stride; z.ph = phase / s; z.pw = phase - z.ph * s;
-    z.th = (5 - z.ph + s - 1) / s; z.tw = (5 - z.pw + s - 1) / s;
+    z.r0h = (z.ph + pad()) % s; z.r0w = (z.pw + pad()) % s;
+    z.th = z.r0h < ks() ? (ks() - z.r0h + s - 1) / s : 0; z.tw = z.r0w < ks() ? (ks() - z.r0w + s - 1) / s : 0;
+    z.bh = (z.ph + pad() - z.r0h) / s; z.bw = (z.pw + pad() - z.r0w) / s;
     const int kall = z.th * z.tw * g.Cs;
     // split at a multiple of 64 so that FAST tiles stay inside one tap / chunk
     const int kh = nsplit > 1 ? (((kall / 64) + 1) / 2) * 64 : kall;
@@ -180,19 +196,18 @@ struct ProbT16 {
     const int t = (int)g.dCs.div((uint32_t)kt);
     const int c = k0 + k8 - t * g.Cs;
     const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-    const int d0 = g.stride == 2 ? 1 : 2;
-    const int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+    const int h = r.q + z.bh - rp, w_ = r.p + z.bw - qp;
     const bool ok = r.valid && kt < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
     return ld16(ok ? small + plane * small_plane + (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c : reinterpret_cast<const u16*>(zero));
   }
-  VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * kTaps * g.Cs; return r; }
+  VP_HD BRow b_row(int n, const ZCtx&) const { BRow r; r.valid = n < N; r.off = (r.valid ? n : 0) * nt() * g.Cs; return r; }
   template <bool FAST>
   VP_HD u32x4_t b_load(const BRow& r, int k0, int k8, int plane, const ZCtx& z) const {
     const int kt = FAST ? k0 : k0 + k8;
     const int t = (int)g.dCs.div((uint32_t)kt);
     const int c = k0 + k8 - t * g.Cs;
     const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-    const int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+    const int tap = (z.r0h + g.stride * rp) * ks() + (z.r0w + g.stride * qp);
     const bool ok = r.valid && kt < z.k_end;
     return ld16(ok ? w + plane * w_plane + (size_t)r.off + tap * g.Cs + c : reinterpret_cast<const u16*>(zero));
   }
@@ -208,8 +223,7 @@ struct ProbT16 {
     int t, c0;
     fast_tile<SH>(k0, z.th * z.tw, t, c0);
     const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-    const int d0 = g.stride == 2 ? 1 : 2;
-    const int h = r.q + d0 - rp, w_ = r.p + d0 - qp;
+    const int h = r.q + z.bh - rp, w_ = r.p + z.bw - qp;
     off = (size_t)(r.pix_base + h * g.Ws + w_) * g.Cs + c0;
     return r.valid && k0 < z.k_end && h >= 0 && h < g.Hs && w_ >= 0 && w_ < g.Ws;
   }
@@ -218,7 +232,7 @@ struct ProbT16 {
     int t, c0;
     fast_tile<SH>(k0, z.th * z.tw, t, c0);
     const int rp = div_small(t, z.tw), qp = t - rp * z.tw;
-    const int tap = (z.ph + g.stride * rp) * 5 + (z.pw + g.stride * qp);
+    const int tap = (z.r0h + g.stride * rp) * ks() + (z.r0w + g.stride * qp);
     off = (size_t)r.off + tap * g.Cs + c0;
     return r.valid && k0 < z.k_end;
   }
@@ -231,6 +245,7 @@ struct ProbT16 {
     int b = (int)g.dHW.div((uint32_t)m); int rem = m - b * (g.Hs * g.Ws);
     int q = (int)g.dW.div((uint32_t)rem), p = rem - q * g.Ws;
     int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
+    if (!K5 && (oh >= g.Hb || ow >= g.Wb)) return;   // odd big sizes: the last phase row/column does not exist
     float* dst = out + ((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (nsplit > 1) { atomicAdd(dst, v); return; }
@@ -238,9 +253,17 @@ struct ProbT16 {
     *dst = v;
   }
 };
+using ProbT16 = ProbT16T<true>;
+using ProbT16K = ProbT16T<false>;
 
 // W family on split planes: slab[split][tap][cs][cb]; both operands pixel-major (KM)
-struct ProbW16 {
+template <bool K5>
+struct ProbW16T {
+  // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
+  // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
+  VP_HD int ks() const { return K5 ? 5 : g.ks; }
+  VP_HD int pad() const { return K5 ? 2 : g.pad; }
+  VP_HD int nt() const { return K5 ? 25 : g.nt; }
   static constexpr bool A_KM = true, B_KM = true;
   const u16* big; size_t big_plane;
   const u16* small; size_t small_plane;
@@ -248,7 +271,7 @@ struct ProbW16 {
   struct ZCtx { int k_begin, k_end, rr, qq, tap, split; };
   VP_HD void z_setup(int zi, ZCtx& z) const {
     z.tap = zi / nsplit; z.split = zi - z.tap * nsplit;
-    z.rr = z.tap / 5; z.qq = z.tap - z.rr * 5;
+    z.rr = z.tap / ks(); z.qq = z.tap - z.rr * ks();
     z.k_begin = z.split * k_per_split;
     int e = z.k_begin + k_per_split; z.k_end = e < K ? e : K;
   }
@@ -259,7 +282,7 @@ struct ProbW16 {
   VP_HD u32x4_t b_load_km(int k, int n, int plane, const ZCtx& z) const {   // big[shifted pixel][n..n+7]
     int b = (int)g.dHW.div((uint32_t)k); int rem = k - b * (g.Hs * g.Ws);
     int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
-    int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
+    int h = g.stride * hs - pad() + z.rr, w_ = g.stride * ws - pad() + z.qq;
     const bool ok = k < z.k_end && n < N && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
     return ld16(ok ? big + plane * big_plane + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb + n : reinterpret_cast<const u16*>(zero));
   }
@@ -271,7 +294,7 @@ struct ProbW16 {
   VP_HD bool b_base_km(int k, const ZCtx& z, size_t& off) const {
     int b = (int)g.dHW.div((uint32_t)k); int rem = k - b * (g.Hs * g.Ws);
     int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
-    int h = g.stride * hs - 2 + z.rr, w_ = g.stride * ws - 2 + z.qq;
+    int h = g.stride * hs - pad() + z.rr, w_ = g.stride * ws - pad() + z.qq;
     off = ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb;
     return k < z.k_end && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
   }
@@ -281,9 +304,11 @@ struct ProbW16 {
   VP_HD size_t b_plane() const { return big_plane; }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
-    slab[(((size_t)z.split * kTaps + z.tap) * M + m) * N + n] = v;
+    slab[(((size_t)z.split * nt() + z.tap) * M + m) * N + n] = v;
   }
 };
+using ProbW16 = ProbW16T<true>;
+using ProbW16K = ProbW16T<false>;
 
 #if defined(__HIPCC__)
 

@@ -222,8 +222,16 @@ class _ConvK(Function):
     def forward(ctx, x, weight, bias, stride: int):
         x = _cl(x)
         ks = weight.shape[2]
-        p0, _ = ops.pack_w(weight, True, False)
-        y = ops.conv_gather(x, p0, bias, ks, stride, ACT_NONE)
+        ctx.x16 = _use16(weight)
+        ctx.xshape = tuple(x.shape)
+        if ctx.x16:                     # split-bf16 kernels (set_conv_precision("bf16x3"), channel counts multiples of 8)
+            xs = ops.split_f32(x)
+            p0, _ = ops.pack_w_split(weight, True, False)
+            y = ops.conv_gather_bf16x3(xs, x.shape, p0, weight.shape[0], bias, ks, stride, ACT_NONE)
+            x = xs
+        else:
+            p0, _ = ops.pack_w(weight, True, False)
+            y = ops.conv_gather(x, p0, bias, ks, stride, ACT_NONE)
         ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
         ctx.save_for_backward(x, weight)
         return y
@@ -233,11 +241,19 @@ class _ConvK(Function):
         x, weight = ctx.saved_tensors
         dy = _cl(dy)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            _, p1 = ops.pack_w(weight, False, True)
-            dx = ops.conv_scatter(dy, p1, ctx.ks, ctx.stride, x.shape[2], x.shape[3])
-        if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(x, dy, ctx.ks, ctx.stride)
+        if ctx.x16:
+            dys = ops.split_f32(dy)
+            if ctx.needs_input_grad[0]:
+                _, p1 = ops.pack_w_split(weight, False, True)
+                dx = ops.conv_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.ks, ctx.stride, ctx.xshape[2], ctx.xshape[3])
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.ks, ctx.stride)
+        else:
+            if ctx.needs_input_grad[0]:
+                _, p1 = ops.pack_w(weight, False, True)
+                dx = ops.conv_scatter(dy, p1, ctx.ks, ctx.stride, x.shape[2], x.shape[3])
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv_wgrad(x, dy, ctx.ks, ctx.stride)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             B, C, H, W = dy.shape
             db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C))

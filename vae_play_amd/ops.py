@@ -513,6 +513,44 @@ def conv_wgrad(big, small, ks: int, stride: int):
     return dw
 
 
+# ---- k x k split-bf16 ("bf16x3") forms ---------------------------------------------------------------------------------
+def pack_w_split(w_ref: torch.Tensor, want_p0: bool, want_p1: bool):
+    Cs, Cb, ks = w_ref.shape[0], w_ref.shape[1], w_ref.shape[2]
+    w_ref = w_ref.contiguous()
+    n = Cs * Cb * ks * ks
+    p0 = empty_split(n, w_ref) if want_p0 else None
+    p1 = empty_split(n, w_ref) if want_p1 else None
+    _lib.call("vp_pack_w_split", _p(w_ref), _pv(p0), _pv(p1), Cs, Cb, ks, _stream())
+    return p0, p1
+
+
+def conv_gather_bf16x3(big_split, shape_big, w_p0_split, Cs: int, bias, ks: int, stride: int, act: int = ACT_NONE):
+    B, Cb, Hb, Wb = shape_big
+    Hs, Ws = conv_out_size(Hb, ks, stride), conv_out_size(Wb, ks, stride)
+    out = torch.empty((B, Cs, Hs, Ws), dtype=torch.float32, device=big_split.device, memory_format=torch.channels_last)
+    _lib.call("vp_conv_gather_bf16x3", _pv(big_split), _pv(w_p0_split), _p(bias), _p(out), B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride, act,
+              _stream())
+    return out
+
+
+def conv_scatter_bf16x3(small_split, shape_small, w_p1_split, Cb: int, ks: int, stride: int, Hb: int, Wb: int):
+    B, Cs, Hs, Ws = shape_small
+    out = torch.empty((B, Cb, Hb, Wb), dtype=torch.float32, device=small_split.device, memory_format=torch.channels_last)
+    _lib.call("vp_conv_scatter_bf16x3", _pv(small_split), _pv(w_p1_split), _p(out), B, Hs, Ws, Hb, Wb, Cs, Cb, ks, stride, _stream())
+    return out
+
+
+def conv_wgrad_bf16x3(big_split, shape_big, small_split, shape_small, ks: int, stride: int):
+    B, Cb, Hb, Wb = shape_big
+    _, Cs, Hs, Ws = shape_small
+    nbytes = _lib.load().vp_conv_wgrad_bf16x3_workspace_bytes(B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride)
+    ws = _ws(nbytes, big_split)
+    dw = torch.empty((Cs, Cb, ks, ks), dtype=torch.float32, device=big_split.device)
+    _lib.call("vp_conv_wgrad_bf16x3", _pv(big_split), _pv(small_split), _p(dw), B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride, _p(ws),
+              ws.numel() * 4, _stream())
+    return dw
+
+
 def upsample2x_fwd(x):
     assert _is_nhwc(x)
     B, C, H, W = x.shape
