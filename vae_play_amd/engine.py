@@ -556,7 +556,7 @@ class FusedVAEStep:
         (Updating each slice right after its all-reduce, on a second side stream underneath the rest of backward, was
         measured and is NOT done: the HBM-bound optimiser kernel slows the concurrent kernels by more than it hides,
         4.52 vs 4.46 ms/step on one GPU; ``optim.*.step_range`` remains available.)"""
-        if self.world > 1 and overlap:
+        if parallel.dp_active(self.group) and overlap:
             g = self.opt.flat_grad
             cut = self._decoder_slice_start()
             dense = self._encoder_dense_start()

@@ -41,9 +41,17 @@ def shard_bounds(global_batch: int, rank: int, world: int) -> tuple:
     return rank * per, (rank + 1) * per
 
 
+def dp_active(group=None) -> bool:
+    """Several ranks, or a one-rank group with VP_DP_FORCE=1 (tools/dp_rccl_selftest.py: drives every collective of
+    the data-parallel step through RCCL on a one-GPU box, where a second rank cannot share the card)."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("VP_DP_FORCE") == "1"
+
+
 def allreduce_flat_grads(flat_grad: torch.Tensor, group=None, async_op: bool = False):
     """The step's single collective: SUM all-reduce of the gradient arena."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dp_active(group):
         return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return None
 
