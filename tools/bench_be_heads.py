@@ -19,8 +19,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32", help="k x k convolutions: exact-f32 MFMA or split-bf16")
     a = ap.parse_args()
     import vae_play_amd.networks_BE as N
+    import vae_play_amd as _V
+    _V.set_conv_precision(a.precision)
     from vae_play_amd import optim
     dev = "cuda"
     torch.manual_seed(0)
@@ -51,7 +54,7 @@ def main():
     out = {"metric": "images/sec (networks_BE heads step, train_BE.py:54-64 below the backbone)", "value": round(a.batch / dt, 1),
            "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3),
            "config": {"workload": f"aux_convs 256->32 + MaskNet + EdgeNet, {a.img}x{a.img} targets, batch {a.batch}",
-                      "path": "autograd modules on HIP kernels (fp32 MFMA)"}, "loss": float(loss)}
+                      "path": f"autograd modules on HIP kernels ({a.precision} convolutions)"}, "loss": float(loss)}
     if a.cpu_steps > 0:
         from oracle import ref_be as BE
         from oracle import ref_cpu as O

@@ -20,8 +20,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32", help="k x k convolutions: exact-f32 MFMA or split-bf16")
     a = ap.parse_args()
     import vae_play_amd.networks_BE as NB
+    import vae_play_amd as _V
+    _V.set_conv_precision(a.precision)
     import vae_play_amd.networks_BE_font as N
     from vae_play_amd import functional as Fh
     from vae_play_amd import optim
@@ -75,7 +78,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     out = {"metric": "images/sec (font GAN iteration, train_BE_font.py:97-170)", "value": round(a.batch / dt, 1), "unit": "images/sec",
            "ms_per_step": round(dt * 1e3, 2), "config": {"workload": f"ComposeNet({a.img}) + Discriminator({a.img}, 2, 143), batch {a.batch}",
-                                                         "path": "autograd modules on HIP kernels (fp32 MFMA)"}, "loss_embed": float(le)}
+                                                         "path": f"autograd modules on HIP kernels ({a.precision} convolutions)"}, "loss_embed": float(le)}
     if a.cpu_steps > 0:
         torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
         O.require_grad(pn); O.require_grad(pd)
