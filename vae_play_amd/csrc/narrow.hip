@@ -92,11 +92,15 @@ __global__ void __launch_bounds__(256) wgrad_narrow_small_kernel(const float* __
   const int lane = threadIdx.x & 63;
   const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = blockIdx.y * 64 + lane;
-  float acc[kTaps][NS];
+  // taps (q0,q1) and (q2,q3) of a tap row share a packed accumulator: their window operands are adjacent registers
+  // and the gradient value is one scalar, so 5 FMAs issue as 2 v_pk_fma_f32 + 1 v_fmac_f32
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 accp[5][2][NS];
+  float acc4[5][NS];
 #pragma unroll
-  for (int t = 0; t < kTaps; ++t)
+  for (int r = 0; r < 5; ++r)
 #pragma unroll
-    for (int n = 0; n < NS; ++n) acc[t][n] = 0.f;
+    for (int n = 0; n < NS; ++n) { accp[r][0][n] = f32x2{0.f, 0.f}; accp[r][1][n] = f32x2{0.f, 0.f}; acc4[r][n] = 0.f; }
   const int unit = blockIdx.x * 4 + g;
   if (unit < nunits) {
     const int strips = (H + NS_ROWS - 1) / NS_ROWS;
@@ -116,30 +120,51 @@ __global__ void __launch_bounds__(256) wgrad_narrow_small_kernel(const float* __
         on[r] = h >= h0 && h < h1;
         sp[r] = small + ((size_t)(b * H + (on[r] ? h : h0)) * W) * NS;
       }
-      float win[8];
+      float win[8], nxt[4];
       win[0] = xa - 2 >= 0 ? bp[(size_t)(xa - 2) * Cb] : 0.f;
       win[1] = xa - 1 >= 0 ? bp[(size_t)(xa - 1) * Cb] : 0.f;
       win[2] = bp[(size_t)xa * Cb];
       win[3] = xa + 1 < W ? bp[(size_t)(xa + 1) * Cb] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nxt[j] = (xa + 2 + j < W) ? bp[(size_t)(xa + 2 + j) * Cb] : 0.f;
       for (int x0 = xa; x0 < xb; x0 += 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) win[4 + j] = (x0 + 2 + j < W) ? bp[(size_t)(x0 + 2 + j) * Cb] : 0.f;
+        for (int j = 0; j < 4; ++j) win[4 + j] = nxt[j];
+        if (x0 + 4 < xb) {                       // the next quad's loads fly underneath this quad's FMAs
+#pragma unroll
+          for (int j = 0; j < 4; ++j) nxt[j] = (x0 + 6 + j < W) ? bp[(size_t)(x0 + 6 + j) * Cb] : 0.f;
+        }
+        const bool full = x0 + 4 <= xb;          // wave-uniform
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
           if (!on[r]) continue;                  // wave-uniform
+          if (full) {
+            // the quad's 4*NS gradient values in one go: wave-uniform address -> wide scalar loads, one wait per quad
+            float sv[4 * NS];
+            const float* s4 = sp[r] + (size_t)x0 * NS;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (x0 + j < xb) {
-              float sv[NS];
+            for (int i = 0; i < 4 * NS; ++i) sv[i] = s4[i];
 #pragma unroll
-              for (int n = 0; n < NS; ++n) sv[n] = sp[r][(x0 + j) * NS + n];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
               for (int n = 0; n < NS; ++n) {
-                acc[r * 5 + 0][n] = fmaf(win[j + 0], sv[n], acc[r * 5 + 0][n]);
-                acc[r * 5 + 1][n] = fmaf(win[j + 1], sv[n], acc[r * 5 + 1][n]);
-                acc[r * 5 + 2][n] = fmaf(win[j + 2], sv[n], acc[r * 5 + 2][n]);
-                acc[r * 5 + 3][n] = fmaf(win[j + 3], sv[n], acc[r * 5 + 3][n]);
-                acc[r * 5 + 4][n] = fmaf(win[j + 4], sv[n], acc[r * 5 + 4][n]);
+                const f32x2 s2 = {sv[j * NS + n], sv[j * NS + n]};
+                accp[r][0][n] = __builtin_elementwise_fma(f32x2{win[j + 0], win[j + 1]}, s2, accp[r][0][n]);
+                accp[r][1][n] = __builtin_elementwise_fma(f32x2{win[j + 2], win[j + 3]}, s2, accp[r][1][n]);
+                acc4[r][n] = fmaf(win[j + 4], sv[j * NS + n], acc4[r][n]);
+              }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (x0 + j < xb) {
+#pragma unroll
+                for (int n = 0; n < NS; ++n) {
+                  const float v = sp[r][(x0 + j) * NS + n];
+                  const f32x2 s2 = {v, v};
+                  accp[r][0][n] = __builtin_elementwise_fma(f32x2{win[j + 0], win[j + 1]}, s2, accp[r][0][n]);
+                  accp[r][1][n] = __builtin_elementwise_fma(f32x2{win[j + 2], win[j + 3]}, s2, accp[r][1][n]);
+                  acc4[r][n] = fmaf(win[j + 4], v, acc4[r][n]);
+                }
               }
             }
           }
@@ -157,7 +182,7 @@ __global__ void __launch_bounds__(256) wgrad_narrow_small_kernel(const float* __
 #pragma unroll
     for (int q = 0; q < 5; ++q)
 #pragma unroll
-      for (int n = 0; n < NS; ++n) red[g][q * NS + n][lane] = acc[r * 5 + q][n];
+      for (int n = 0; n < NS; ++n) red[g][q * NS + n][lane] = q < 4 ? accp[r][q >> 1][n][q & 1] : acc4[r][n];
     __syncthreads();
     for (int i = g; i < 5 * NS; i += 4) {
       const float v = (red[0][i][lane] + red[1][i][lane]) + (red[2][i][lane] + red[3][i][lane]);
