@@ -73,7 +73,10 @@ def test_conv5_gather_scatter_wgrad(B, Hs, Cb, Cs, stride):
 
 
 @pytest.mark.parametrize("M,N,K", [(4, 16, 64), (32, 1024, 32768), (32, 128, 1024), (5, 7, 9), (130, 70, 33),
-                                   (32, 32768, 128), (256, 512, 384)])
+                                   (32, 32768, 128), (256, 512, 384),
+                                   # skinny kernels (batch-sized M, weights streamed once): ragged M, N off the 128-column
+                                   # block, odd tile counts per wave, split and unsplit K
+                                   (7, 200, 320), (32, 132, 4096), (1, 1000, 192), (31, 4100, 64), (16, 256, 8192), (9, 320, 200), (3, 448, 132)])
 def test_linear_forms(M, N, K):
     from vae_play_amd import ops
     g = torch.Generator().manual_seed(M + N + K)

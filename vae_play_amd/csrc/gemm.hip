@@ -17,6 +17,36 @@ __global__ void gemm_reduce_kernel(const float* __restrict__ slab, float* __rest
   }
 }
 
+// Few outputs, many slabs (a 32 x 128 input gradient contracted over 32768 features in 128 splits): one thread per output
+// walked the slabs as 128 dependent loads (38 us for 4096 outputs).  Here 64 outputs x 4 split-lanes per workgroup, four
+// loads in flight per lane, combined through LDS in a fixed order.
+__global__ void __launch_bounds__(256) gemm_reduce_deep_kernel(const float* __restrict__ slab, float* __restrict__ C,
+                                                               const float* __restrict__ bias, int M, int N, int ldc, int nsplit) {
+  __shared__ float red[4][64];
+  const size_t per = (size_t)M * N;
+  const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < per) {
+    int sp = sl;
+    for (; sp + 12 < nsplit; sp += 16) {
+      s0 += slab[(size_t)sp * per + i];
+      s1 += slab[(size_t)(sp + 4) * per + i];
+      s2 += slab[(size_t)(sp + 8) * per + i];
+      s3 += slab[(size_t)(sp + 12) * per + i];
+    }
+    for (; sp < nsplit; sp += 4) s0 += slab[(size_t)sp * per + i];
+  }
+  red[sl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && i < per) {
+    const int n = (int)(i % N);
+    const size_t m = i / N;
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    C[m * ldc + n] = v + (bias ? bias[n] : 0.f);
+  }
+}
+
 // partial[chunk][c] = sum over the chunk's rows of x[r][c]; generic C (bias grads have C = 3).
 __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int R, int C, int rows_per_chunk) {
   const int chunk = blockIdx.x;
@@ -52,6 +82,182 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
   if (threadIdx.x == 0) out[c] = (float)s;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Skinny dense layers: M <= 32 rows (the batch) against a weight matrix that is read exactly once -- HBM-bound.
+// The general tile kernel stages BOTH operands through LDS with two barriers per K-tile and reached 2-3 TB/s on the
+// 134 MB encoder.fc.0 matrix.  Here the weights go straight from global memory into the MFMA B operand (each element
+// is used by one wave only, so LDS buys nothing), eight 16-B loads in flight per lane, and only the activation rows
+// (a few MB, L2-resident) are shared.  v_mfma_f32_32x32x2_f32: exact fp32, the 32 batch rows are the MFMA's M.
+// The k order inside a tile is permuted identically for A and B (mode 0: lane half h, load i, step j <-> k = 32 h + 4 i + j,
+// so that a lane walks one 128-B line of its weight row per tile; mode 1: k = 8 q + 4 h + j).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SK_KT = 64;   // k per tile
+
+// mode 0 (Linear forward): A[m][k] and B[n][k] both k-contiguous.  Workgroup = 4 waves x 32 columns; the A tile
+// [32][64] is shared through LDS (two buffers, one barrier per tile).  grid = (ceil(N/128), nsplit).
+__global__ void __launch_bounds__(256) skinny_mk_kernel(const float* __restrict__ A, long sam, const float* __restrict__ Bm, long sbn,
+                                                        float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
+                                                        int K, int nsplit, int kps) {
+  __shared__ __attribute__((aligned(16))) float xs[2][32][SK_KT + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.x * 128 + wave * 32 + li;
+  const float* wrow = Bm + (size_t)(n < N ? n : 0) * sbn;
+  const int k_begin = blockIdx.y * kps;
+  const int k_end = min(K, k_begin + kps);
+  const int nk = (k_end - k_begin) / SK_KT;
+  const int xrow = tid >> 3, xc = tid & 7;
+  const float* arow = A + (size_t)(xrow < M ? xrow : 0) * sam;
+  const bool xok = xrow < M;
+  vp_f32x4 xr0, xr1, w[8], wn[8];
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  auto load_tile = [&](int kb) {
+    xr0 = xok ? ld4(arow + kb + xc * 4) : zero4();
+    xr1 = xok ? ld4(arow + kb + 32 + xc * 4) : zero4();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wn[i] = ld4(wrow + kb + lh * 32 + i * 4);   // one 128-B line per lane and tile
+  };
+  auto write_x = [&](int buf) {
+    *reinterpret_cast<vp_f32x4*>(&xs[buf][xrow][xc * 4]) = xr0;
+    *reinterpret_cast<vp_f32x4*>(&xs[buf][xrow][32 + xc * 4]) = xr1;
+  };
+  if (nk > 0) {
+    load_tile(k_begin);
+    write_x(0);
+    __syncthreads();
+  }
+  for (int t = 0; t < nk; ++t) {
+    const bool more = t + 1 < nk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = wn[i];
+    if (more) load_tile(k_begin + (t + 1) * SK_KT);
+    const int cur = t & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const vp_f32x4 x4 = *reinterpret_cast<const vp_f32x4*>(&xs[cur][li][lh * 32 + i * 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[j], w[i][j], acc, 0, 0, 0);
+    }
+    if (more) write_x(cur ^ 1);      // last read in iteration t-1, which every wave left through the barrier below
+    __syncthreads();
+  }
+  if (n >= N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m >= M) continue;
+    if (nsplit == 1) C[(size_t)m * ldc + n] = acc[r] + (bias ? bias[n] : 0.f);
+    else C[((size_t)blockIdx.y * M + m) * N + n] = acc[r];
+  }
+}
+
+// mode 1 (Linear input gradient): A[m][k] k-contiguous, B[k][n] n-contiguous.  A lane's 16-B weight load covers 4 columns of
+// one k row, so a wave owns 128 columns (4 accumulators) and reuses its A value four times; the 4 waves of a workgroup take
+// interleaved 64-deep k tiles of the workgroup's K range and are summed through LDS in a fixed order at the end.  No barrier
+// in the main loop: the A values (L2-resident) are loaded per lane as well.  grid = (ceil(N/128), nsplit).
+__global__ void __launch_bounds__(256) skinny_kn_kernel(const float* __restrict__ A, long sam, const float* __restrict__ Bm, long sbk,
+                                                        float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
+                                                        int K, int nsplit, int kps) {
+  __shared__ __attribute__((aligned(16))) float red[2][64][64];   // [wave slot][register][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 128 + 4 * li;           // this lane's 4 columns (N % 4 == 0)
+  const bool nok = n0 < N;
+  const float* wcol = Bm + (nok ? n0 : 0);
+  const float* arow = A + (size_t)(li < M ? li : 0) * sam;
+  const bool aok = li < M;
+  const int k_begin = blockIdx.y * kps;
+  const int k_end = min(K, k_begin + kps);
+  const int nk = (k_end - k_begin) / SK_KT;          // tiles of the workgroup; wave w takes tiles w, w+4, ...
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  vp_f32x4 w[8], wn[8], a[2], an[2];
+  // half a tile (32 k) per step: q = 0..3 blocks of 8 k; lane half h, step j <-> k = kb + 8 q + 4 h + j
+  auto load_half = [&](int kb) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      an[q] = aok ? ld4(arow + kb + q * 8 + lh * 4) : zero4();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wn[q * 4 + j] = ld4(wcol + (size_t)(kb + q * 8 + lh * 4 + j) * sbk);
+    }
+  };
+  const int nh = nk > wave ? ((nk - wave + 3) / 4) * 4 : 0;   // 16-k-row steps of this wave: 4 per tile
+  auto kb_of = [&](int h) { return k_begin + (wave + 4 * (h >> 2)) * SK_KT + (h & 3) * 16; };
+  if (nh > 0) load_half(kb_of(0));
+  for (int h = 0; h < nh; ++h) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = wn[i];
+    a[0] = an[0]; a[1] = an[1];
+    if (h + 1 < nh) load_half(kb_of(h + 1));
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], w[q * 4 + j][c], acc[c], 0, 0, 0);
+  }
+  // (wave 2, wave 3) -> LDS, added by (wave 0, wave 1); then wave 1 -> LDS, added by wave 0
+  if (wave >= 2) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 2][c * 16 + r][lane] = acc[c][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] += red[wave][c * 16 + r][lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[0][c * 16 + r][lane] = acc[c][r];
+  }
+  __syncthreads();
+  if (wave != 0 || !nok) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m >= M) continue;
+    vp_f32x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = acc[c][r] + red[0][c * 16 + r][lane];
+    if (nsplit == 1) {
+      if (bias) { v[0] += bias[n0]; v[1] += bias[n0 + 1]; v[2] += bias[n0 + 2]; v[3] += bias[n0 + 3]; }
+      *reinterpret_cast<vp_f32x4*>(C + (size_t)m * ldc + n0) = v;
+    } else {
+      *reinterpret_cast<vp_f32x4*>(C + ((size_t)blockIdx.y * M + m) * N + n0) = v;
+    }
+  }
+}
+
+// Split count of the skinny kernels (0: shape not eligible).  mode 0 / 1 as in vp_gemm_f32.
+inline int skinny_nsplit(int mode, long M, long N, long K) {
+  if (mode > 1 || M > 32 || N < 128 || K % SK_KT) return 0;
+  if (const char* e = getenv("VP_GEMM_SKINNY")) if (atoi(e) == 0) return 0;   // A/B knob
+  const long colblocks = (N + 127) / 128;
+  const long unit = mode == 0 ? 256 : 4 * SK_KT;      // smallest K range worth a workgroup
+  long want = (512 + colblocks - 1) / colblocks;
+  long maxs = K / unit;
+  if (maxs < 1) maxs = 1;
+  long s = want < maxs ? want : maxs;
+  if (s > 128) s = 128;
+  return (int)s;
+}
+inline int skinny_kps(long K, int ns) {
+  const long per = (K + ns - 1) / ns;
+  return (int)(((per + SK_KT - 1) / SK_KT) * SK_KT);
+}
+
 inline int colsum_chunks(int R) {
   int n = (R + 511) / 512;
   if (n > 1024) n = 1024;
@@ -66,7 +272,11 @@ using namespace vp;
 extern "C" {
 
 size_t vp_gemm_workspace_bytes(int M, int N, int K) {
-  const int ns = gemm_nsplit(M, N, K);
+  int ns = gemm_nsplit(M, N, K);
+  for (int mode = 0; mode < 2; ++mode) {          // the caller does not name the mode here: cover the skinny kernels' split too
+    const int s0 = skinny_nsplit(mode, M, N, K);
+    if (s0) { const int kps = skinny_kps(K, s0); const int eff = (K + kps - 1) / kps; if (eff > ns) ns = eff; }
+  }
   return ns > 1 ? (size_t)ns * M * N * sizeof(float) : 0;
 }
 
@@ -75,7 +285,32 @@ int vp_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, lo
   VP_REQUIRE(A && B && C, "vp_gemm_f32: null pointer");
   VP_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, "vp_gemm_f32: bad shape M=%d N=%d K=%d ldc=%d", M, N, K, ldc);
   VP_REQUIRE(mode >= 0 && mode <= 2, "vp_gemm_f32: mode must be 0|1|2");
-  const int ns = gemm_nsplit(M, N, K);
+  int ns = gemm_nsplit(M, N, K);
+  // skinny path: batch-sized M, the weight matrix streamed once straight into the MFMA operand
+  const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  int sk = skinny_nsplit(mode, M, N, K);
+  if (sk && mode == 0 && !(sak == 1 && sbk == 1 && sam % 4 == 0 && sbn % 4 == 0 && al16(A) && al16(B))) sk = 0;
+  if (sk && mode == 1 && !(sak == 1 && sbn == 1 && sam % 4 == 0 && sbk % 4 == 0 && N % 4 == 0 && ldc % 4 == 0 && al16(A) && al16(B) && al16(C))) sk = 0;
+  if (sk) {
+    const int kps = skinny_kps(K, sk);
+    ns = (K + kps - 1) / kps;
+    float* dst = C;
+    if (ns > 1) {
+      if (!ws || ws_bytes < (size_t)ns * M * N * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_gemm_f32: workspace too small");
+      dst = (float*)ws;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)ns);
+    if (mode == 0) hipLaunchKernelGGL(skinny_mk_kernel, grid, dim3(256), 0, s, A, sam, B, sbn, dst, ldc, bias, M, N, K, ns, kps);
+    else hipLaunchKernelGGL(skinny_kn_kernel, grid, dim3(256), 0, s, A, sam, B, sbk, dst, ldc, bias, M, N, K, ns, kps);
+    int rc = check_launch("vp_gemm_f32(skinny)");
+    if (rc || ns == 1) return rc;
+    if (ns >= 16 && (size_t)M * N <= 65536)
+      hipLaunchKernelGGL(gemm_reduce_deep_kernel, dim3((unsigned)(((size_t)M * N + 63) / 64)), dim3(256), 0, s, (const float*)ws, C, bias, M, N, ldc, ns);
+    else
+      hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N, 256)), dim3(256), 0, s, (const float*)ws, C, bias, M, N, ldc, ns);
+    return check_launch("vp_gemm_f32(reduce)");
+  }
   float* dst = C;
   if (ns > 1) {
     const size_t need = (size_t)ns * M * N * sizeof(float);
@@ -95,7 +330,10 @@ int vp_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, lo
   }
   int rc = check_launch("vp_gemm_f32(main)");
   if (rc || ns == 1) return rc;
-  hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N, 256)), dim3(256), 0, s, (const float*)ws, C, bias, M, N, ldc, ns);
+  if (ns >= 16 && (size_t)M * N <= 65536)
+    hipLaunchKernelGGL(gemm_reduce_deep_kernel, dim3((unsigned)(((size_t)M * N + 63) / 64)), dim3(256), 0, s, (const float*)ws, C, bias, M, N, ldc, ns);
+  else
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid_for((size_t)M * N, 256)), dim3(256), 0, s, (const float*)ws, C, bias, M, N, ldc, ns);
   return check_launch("vp_gemm_f32(reduce)");
 }
 
