@@ -163,3 +163,71 @@ def test_dp_two_ranks_on_one_gpu_matches_oracle_definition():
             d_ = (res[r]["params"][n] - new_params[n]).abs()
             assert (d_ > 1e-5).double().mean().item() < 1e-3, f"rank {r} param {n}"
         assert torch.equal(res[0]["params"][n], res[1]["params"][n]), f"replicas diverged: {n}"
+
+
+# ---- several optimisers over shared parameters (VAE-GAN / font GAN): parallel.DataParallelGroup -----------------------
+def _group_model(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: torch.nn.Parameter((torch.randn(*s, generator=g) * 0.3).cuda())
+    return mk(6, 5), mk(5, 4), mk(4, 3)
+
+
+def _group_loss(ws, x, phase):
+    w1, w2, w3 = ws
+    h = torch.tanh(x @ w1) @ w2
+    return (h ** 2).mean() if phase == 0 else (torch.tanh(h) @ w3).abs().mean()
+
+
+def _group_data(rank):
+    return torch.randn(4, 6, generator=torch.Generator().manual_seed(100 + rank)).cuda()
+
+
+def _worker_group(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK="0")
+    from vae_play_amd import optim, parallel
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    ws = _group_model()
+    opt_a = optim.Adam([ws[0], ws[1]], lr=1e-2)          # owns w1, w2
+    opt_b = optim.RMSprop([ws[1], ws[2]], lr=1e-2)       # w2 is shared (lives in opt_a's arena), owns w3
+    grp = parallel.DataParallelGroup([opt_a, opt_b])
+    x = _group_data(rank)
+    grp.zero_grad()
+    _group_loss(ws, x, 0).backward()
+    grp.step(subset=[opt_a])                             # phase 1: only the first optimiser
+    grp.zero_grad()
+    _group_loss(ws, x, 1).backward()
+    grp.step(subset=[opt_b])                             # phase 2: steps the shared w2 whose arena is not part of the phase
+    grp.zero_grad()
+    _group_loss(ws, x, 1).backward()
+    grp.step()                                           # both at once: w2's gradient must be reduced once, not twice
+    torch.cuda.synchronize()
+    torch.save([w.detach().cpu() for w in ws], os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_dp_group_shared_parameters_two_ranks_one_gpu():
+    from vae_play_amd import optim
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_group, args=(_free_port(), d), nprocs=WORLD, join=True)
+        res = [torch.load(os.path.join(d, f"g{r}.pt"), weights_only=True) for r in range(WORLD)]
+    # single-process statement: average the two shards' gradients by hand, same optimisers with grad_scale 1
+    ws = _group_model()
+    opt_a = optim.Adam([ws[0], ws[1]], lr=1e-2)
+    opt_b = optim.RMSprop([ws[1], ws[2]], lr=1e-2)
+    xs = [_group_data(r) for r in range(WORLD)]
+
+    def averaged_backward(phase):
+        opt_a.zero_grad(); opt_b.zero_grad()
+        sum(_group_loss(ws, x, phase) / WORLD for x in xs).backward()
+
+    averaged_backward(0); opt_a.step()
+    averaged_backward(1); opt_b.step()
+    averaged_backward(1); opt_a.step(); opt_b.step()
+    torch.cuda.synchronize()
+    for i, w in enumerate(ws):
+        assert torch.equal(res[0][i], res[1][i]), f"replicas diverged: w{i + 1}"
+        err = (res[0][i] - w.detach().cpu()).abs().max().item() / w.detach().abs().max().item()
+        assert err < 1e-5, f"w{i + 1}: rel err {err}"

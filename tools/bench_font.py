@@ -27,9 +27,14 @@ def main():
     _V.set_conv_precision(a.precision)
     import vae_play_amd.networks_BE_font as N
     from vae_play_amd import functional as Fh
-    from vae_play_amd import optim
+    from vae_play_amd import optim, parallel
     from oracle import ref_cpu as O
     from oracle import ref_font as FN
+    # one process per GPU under torchrun (BASELINE config 5: 8 x MI355X): --batch images PER RANK; every phase all-reduces
+    # (averages) the gradients it is about to apply; VP_BENCH_BACKEND=gloo rehearses it with several ranks on one GPU
+    rank, world, local = parallel.init_from_env(os.environ.get("VP_BENCH_BACKEND"))
+    if os.environ.get("VP_BENCH_BACKEND", "nccl") == "nccl":
+        torch.cuda.set_device(local)
     dev = "cuda"
     torch.manual_seed(0)
     net = NB.initialize_model(N.ComposeNet(a.img))
@@ -39,6 +44,14 @@ def main():
     net, disc = net.to(dev).train(), disc.to(dev).train()
     opt, opt_style, opt_disc = optim.Adam(net.parameters(), lr=1e-4), optim.Adam(net.style_encoder.parameters(), lr=1e-4), \
         optim.Adam(disc.parameters(), lr=1e-4)
+    dp = parallel.DataParallelGroup([opt, opt_style, opt_disc]) if world > 1 else None
+
+    def apply(o):
+        if dp is not None:
+            dp.step(subset=[o])
+        else:
+            o.step()
+
     imgs, masks, edges, labels, y = FN.synthetic_batch(a.batch, a.img)
     dimgs, dmasks, dedges, dlabels = imgs.to(dev), masks.to(dev), edges.to(dev), labels.to(dev)
     dy = {k: v.to(dev) for k, v in y.items()}
@@ -52,33 +65,48 @@ def main():
         d_pr_adv, _ = disc(pm, dy)
         opt_disc.zero_grad()
         ((F.binary_cross_entropy(d_gt_adv, ones) + F.binary_cross_entropy(d_pr_adv, zeros)) * 0.5 + F.cross_entropy(d_gt_aux, dlabels)).backward()
-        opt_disc.step()
+        apply(opt_disc)
         pr = net(dimgs, dy)
         g_adv, g_aux = disc(torch.cat([pr["masks"], pr["edges"]], dim=1), dy)
         opt.zero_grad()
         l_gadv = F.binary_cross_entropy(g_adv, ones) * 2
         (NB.be_loss(pr["edges"], dedges) * 10 + NB.be_loss(pr["masks"], dmasks) * 10 + l_gadv + l_gadv * 5).backward()
-        opt.step()
+        apply(opt)
         with torch.no_grad():
             ref = net(dimgs, dy)
         pr_ = net(dimgs)
         opt_style.zero_grad()
         l_embed = (Fh.l1_loss(pr_["masks"], ref["masks"]) + Fh.l1_loss(pr_["edges"], ref["edges"])) * 2.0
         (NB.be_loss(pr_["masks"], dmasks) + NB.be_loss(pr_["edges"], dedges) + l_embed).backward()
-        opt_style.step()
+        apply(opt_style)
         return l_embed
 
     for _ in range(a.warmup):
         iteration()
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         le = iteration()
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     dt = (time.perf_counter() - t0) / a.steps
-    out = {"metric": "images/sec (font GAN iteration, train_BE_font.py:97-170)", "value": round(a.batch / dt, 1), "unit": "images/sec",
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    out = {"metric": "images/sec (font GAN iteration, train_BE_font.py:97-170)", "value": round(world * a.batch / dt, 1), "unit": "images/sec",
+           "n_gpus": world, "scaling": "weak",
            "ms_per_step": round(dt * 1e3, 2), "config": {"workload": f"ComposeNet({a.img}) + Discriminator({a.img}, 2, 143), batch {a.batch}",
-                                                         "path": f"autograd modules on HIP kernels ({a.precision} convolutions)"}, "loss_embed": float(le)}
+                                                         "path": f"autograd modules on HIP kernels ({a.precision} convolutions)"}, "loss_embed": float(le.detach())}
+    if world > 1:
+        if rank == 0:
+            print(json.dumps(out))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
     if a.cpu_steps > 0:
         torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
         O.require_grad(pn); O.require_grad(pd)

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def step(net, opts, x, targets, eps, z_p, V, lam, fused=True):
+def step(net, opts, x, targets, eps, z_p, V, lam, fused=True, dp=None):
     B = x.size(0)
     x_tilde, disc_class, disc_layer, mus, logvar, params = net(x, eps=eps, z_p=z_p)
     dl = (disc_layer[:B], disc_layer[B:-B], disc_layer[-B:])
@@ -34,8 +34,11 @@ def step(net, opts, x, targets, eps, z_p, V, lam, fused=True):
         loss_decoder.backward(retain_graph=True)
         loss_disc.backward(retain_graph=True)
         l1.backward()
-    for o in opts:
-        o.step()
+    if dp is not None:
+        dp.step()           # under torchrun: one all-reduce per gradient arena, then the fused updates
+    else:
+        for o in opts:
+            o.step()
     return loss_encoder
 
 
@@ -51,30 +54,51 @@ def main():
     ap.add_argument("--five-pass", action="store_true", help="the reference's five backward(retain_graph=True) calls instead of one")
     a = ap.parse_args()
     import vae_play_amd as V
-    from vae_play_amd import optim
+    from vae_play_amd import optim, parallel
+    # one process per GPU under torchrun (BASELINE config 4: 4 x MI355X): --batch images PER RANK, the four gradient arenas
+    # all-reduced (averaged) before their updates; VP_BENCH_BACKEND=gloo rehearses it with several ranks on one GPU
+    rank, world, local = parallel.init_from_env(os.environ.get("VP_BENCH_BACKEND"))
+    if os.environ.get("VP_BENCH_BACKEND", "nccl") == "nccl":
+        torch.cuda.set_device(local)
     dev = "cuda"
     V.set_conv_precision(a.precision)
     torch.manual_seed(0)
     net = V.VaeGan(a.img, a.z).to(dev).train()
     opts = [optim.RMSprop(m.parameters(), lr=1e-4) for m in (net.encoder, net.decoder, net.discriminator, net.param_encoder)]
-    g = torch.Generator().manual_seed(1)
+    dp = parallel.DataParallelGroup(opts) if world > 1 else None
+    g = torch.Generator().manual_seed(1 + rank)
     x = torch.rand(a.batch, 1, a.img, a.img, generator=g).to(dev)
     targets = torch.rand(a.batch, 3, generator=g).to(dev)
     eps = torch.randn(a.batch, a.z, generator=g).to(dev)
     z_p = torch.randn(a.batch, a.z, generator=g).to(dev)
     for _ in range(a.warmup):
-        step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass)
+        step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass, dp)
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass)
+        loss = step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass, dp)
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     dt = (time.perf_counter() - t0) / a.steps
-    out = {"metric": "images/sec (VAE-GAN train step, train.py:43-78)", "value": round(a.batch / dt, 1), "unit": "images/sec",
-           "ms_per_step": round(dt * 1e3, 3), "config": {"workload": f"VaeGan {a.img}x{a.img}x1 z={a.z} batch {a.batch}",
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    out = {"metric": "images/sec (VAE-GAN train step, train.py:43-78)", "value": round(world * a.batch / dt, 1), "unit": "images/sec",
+           "n_gpus": world, "scaling": "weak",
+           "ms_per_step": round(dt * 1e3, 3), "config": {"workload": f"VaeGan {a.img}x{a.img}x1 z={a.z} batch {a.batch} per rank",
                                                          "path": f"autograd modules on HIP kernels ({a.precision} convolutions)",
                                                          "backward": "five passes (train.py:69-73)" if a.five_pass else "one pass over the summed losses"},
-           "loss_encoder": float(loss)}
+           "loss_encoder": float(loss.detach())}
+    if world > 1:
+        if rank == 0:
+            print(json.dumps(out))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
     if a.cpu_steps > 0:
         from oracle import ref_cpu as O
         from oracle import ref_vaegan as G

@@ -91,3 +91,52 @@ class DataParallelStep:
     def step(self) -> None:
         allreduce_flat_grads(self.optimizer.flat_grad, self.group)
         self.optimizer.step()
+
+
+class DataParallelGroup:
+    """Several flat-arena optimisers over one model family (the VAE-GAN's four, the font GAN's three): ``step()`` brings
+    every gradient into its arena, sum-all-reduces each arena ONCE (parameters shared between optimisers live in one
+    arena only, so their gradient is reduced once too) and then runs the fused updates with the 1/W factor folded in.
+
+        for o in opts: o.zero_grad()
+        loss.backward()
+        group.step()                      # instead of: for o in opts: o.step()
+    """
+
+    def __init__(self, optimizers, group=None, broadcast_from: Optional[int] = 0):
+        self.optimizers, self.group = list(optimizers), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        for o in self.optimizers:
+            o.grad_scale = 1.0 / self.world
+            if broadcast_from is not None:
+                broadcast_flat_params(o.flat_param, broadcast_from, group)
+
+    def zero_grad(self) -> None:
+        for o in self.optimizers:
+            o.zero_grad()
+
+    def step(self, subset=None) -> None:
+        """``subset``: the optimisers to step now (a phase of a GAN iteration); default all."""
+        opts = self.optimizers if subset is None else list(subset)
+        for o in opts:
+            if o.arena.numel:
+                o.arena.gather_grads()
+        works = [allreduce_flat_grads(o.flat_grad, self.group, async_op=True) for o in opts if o.arena.numel]
+        # a shared parameter whose owning arena is not part of this phase (the font GAN's style-encoder optimiser steps
+        # parameters that live in the generator's arena): reduce its gradient on its own
+        owners = {id(o.arena) for o in opts if o.arena.numel}
+        for o in opts:
+            for q in o.arena.foreign:
+                if q.grad is not None and id(getattr(q, "_vp_arena", None)) not in owners:
+                    g = q.grad if q.grad.is_contiguous() else q.grad.contiguous()
+                    w = allreduce_flat_grads(g, self.group, async_op=True)
+                    if g is not q.grad and w is not None:
+                        w.wait()
+                        q.grad.copy_(g)
+                    else:
+                        works.append(w)
+        for w in works:
+            if w is not None:
+                w.wait()
+        for o in opts:
+            o.step()
