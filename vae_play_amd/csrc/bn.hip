@@ -39,6 +39,13 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     default: return v;
   }
 }
+// pre-activation of the normalised value: gamma * ((x - mean) * rstd) + beta, written ONCE so that forward and backward
+// round it identically (the backward kernels rebuild the activation mask from it).  The hoisted form x * scale + shift
+// with shift = beta - mean * scale cancels two terms of size |mean| / sigma: for Linear -> BatchNorm1d over a few similar
+// samples (|mean| / sigma ~ 1e3) that cost three digits of y and made the VAE-GAN gradients 10-50 x noisier than torch's.
+__device__ __forceinline__ float bn_pre(float x, float mu, float rs, float ga, float be) {
+  return fmaf(ga, (x - mu) * rs, be);
+}
 // derivative of act at pre-activation value u
 __device__ __forceinline__ float act_grad_pre(float u, int act, float slope) {
   switch (act) {
@@ -75,17 +82,22 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
     rs[j] = (MODE == 1 && ok) ? rstd[c + j] : 0.f;
     ga[j] = (MODE == 1 && ok && gamma) ? gamma[c + j] : 1.f;
     be[j] = (MODE == 1 && ok && beta) ? beta[c + j] : 0.f;
+    // MODE 0 sums (x - pivot) and (x - pivot)^2 with pivot = the channel's value in row 0 (bn_stats_final adds it back):
+    // E[x^2] - E[x]^2 on raw values loses log2(mean^2 / var) bits, which for a Linear -> BatchNorm1d over a batch of 4
+    // similar images (mean^2 / var ~ 1e3-1e4) turned 2e-7 of input rounding into 1e-3 of sigma
+    if (MODE == 0) mu[j] = ok ? x[c + j] : 0.f;
   }
   if (c < C) {
     auto accum = [&](const float (&xv)[4], const float (&gv)[4]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (MODE == 0) {
-          s0[j] += xv[j];
-          s1[j] += xv[j] * xv[j];
+          const float d = xv[j] - mu[j];
+          s0[j] += d;
+          s1[j] += d * d;
         } else {
           const float xh = (xv[j] - mu[j]) * rs[j];
-          const float g = gv[j] * act_grad_pre(ga[j] * xh + be[j], act, slope);
+          const float g = gv[j] * act_grad_pre(fmaf(ga[j], xh, be[j]), act, slope);
           s0[j] += g;
           s1[j] += g * xh;
         }
@@ -175,15 +187,17 @@ __device__ __forceinline__ void bn_final_reduce(const float* __restrict__ part, 
 
 __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __restrict__ part, int nchunk, int R, int C, float eps,
                                                              float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                                             float* __restrict__ rm, float* __restrict__ rv, size_t bps = 0) {
-  part += blockIdx.z * bps; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
+                                                             float* __restrict__ rm, float* __restrict__ rv, const float* __restrict__ x,
+                                                             size_t bps = 0, size_t bxs = 0) {
+  part += blockIdx.z * bps; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C; x += blockIdx.z * bxs;
   const int c = blockIdx.x * FIN_C + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   double s, q;
   bn_final_reduce(part, nchunk, C, c, lane, s, q);
   if (lane != 0 || c >= C) return;
-  const double m = s / R;
-  double var = q / R - m * m;
+  const double ms = s / R;                 // mean of (x - pivot), pivot = x[row 0][c] as in bn_partial_kernel<0>
+  double var = q / R - ms * ms;
   if (var < 0.0) var = 0.0;
+  const double m = (double)x[c] + ms;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
   if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
@@ -207,7 +221,7 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* __restri
   if (dgamma) dgamma[c] = (float)q;
 }
 
-// y = act(x*scale + shift)
+// y = act(gamma * (x - mean) * rstd + beta)
 __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, size_t n,
@@ -225,9 +239,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
       vp_f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float sc = rstd[c + j] * (gamma ? gamma[c + j] : 1.f);
-        const float sf = (beta ? beta[c + j] : 0.f) - mean[c + j] * sc;
-        o[j] = act_apply(v[j] * sc + sf, act, slope);
+        o[j] = act_apply(bn_pre(v[j], mean[c + j], rstd[c + j], gamma ? gamma[c + j] : 1.f, beta ? beta[c + j] : 0.f), act, slope);
       }
       if (y) *reinterpret_cast<vp_f32x4*>(y + i * 4) = o;
       if (y_split) store_split4(y_split, n, i * 4, o[0], o[1], o[2], o[3]);
@@ -235,9 +247,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
       const int c = (int)(i % C);
-      const float sc = rstd[c] * (gamma ? gamma[c] : 1.f);
-      const float sf = (beta ? beta[c] : 0.f) - mean[c] * sc;
-      y[i] = act_apply(x[i] * sc + sf, act, slope);
+      y[i] = act_apply(bn_pre(x[i], mean[c], rstd[c], gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f), act, slope);
     }
   }
 }
@@ -264,7 +274,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
       for (int j = 0; j < 4; ++j) {
         const float ga = gamma ? gamma[c + j] : 1.f, be = beta ? beta[c + j] : 0.f;
         const float xh = (xv[j] - mean[c + j]) * rstd[c + j];
-        const float g = dv[j] * act_grad_pre(ga * xh + be, act, slope);
+        const float g = dv[j] * act_grad_pre(fmaf(ga, xh, be), act, slope);
         o[j] = ga * rstd[c + j] * (g - (sum_g[c + j] + xh * sum_gx[c + j]) * invR);
       }
       if (dx) *reinterpret_cast<vp_f32x4*>(dx + i * 4) = o;
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
       const int c = (int)(i % C);
       const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
       const float xh = (x[i] - mean[c]) * rstd[c];
-      const float g = dy[i] * act_grad_pre(ga * xh + be, act, slope);
+      const float g = dy[i] * act_grad_pre(fmaf(ga, xh, be), act, slope);
       dx[i] = ga * rstd[c] * (g - (sum_g[c] + xh * sum_gx[c]) * invR);
     }
   }
@@ -312,11 +322,11 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
   const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
   const int c = blockIdx.y * BN_CH + tx * 4;
   if (c >= C) return;
-  float sc[4], sf[4];
+  float mu[4], rs[4], ga[4], be[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    sc[j] = rstd[c + j] * (gamma ? gamma[c + j] : 1.f);
-    sf[j] = (beta ? beta[c + j] : 0.f) - mean[c + j] * sc[j];
+    mu[j] = mean[c + j]; rs[j] = rstd[c + j];
+    ga[j] = gamma ? gamma[c + j] : 1.f; be[j] = beta ? beta[c + j] : 0.f;
   }
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(R, r0 + rows_per_chunk);
@@ -333,7 +343,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
       const size_t off = (size_t)(r + u * BN_TY) * C + c;
       vp_f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = act_apply(v[u][j] * sc[j] + sf[j], act, slope);
+      for (int j = 0; j < 4; ++j) o[j] = act_apply(bn_pre(v[u][j], mu[j], rs[j], ga[j], be[j]), act, slope);
       if (y) *reinterpret_cast<vp_f32x4*>(y + off) = o;
       if (y_split) store_split4(y_split, n, off, o[0], o[1], o[2], o[3]);
     }
@@ -343,7 +353,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
     const vp_f32x4 v = *reinterpret_cast<const vp_f32x4*>(x + off);
     vp_f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = act_apply(v[j] * sc[j] + sf[j], act, slope);
+    for (int j = 0; j < 4; ++j) o[j] = act_apply(bn_pre(v[j], mu[j], rs[j], ga[j], be[j]), act, slope);
     if (y) *reinterpret_cast<vp_f32x4*>(y + off) = o;
     if (y_split) store_split4(y_split, n, off, o[0], o[1], o[2], o[3]);
   }
@@ -377,7 +387,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float xh = (xv[j] - mu[j]) * rs[j];
-      const float g = dv[j] * act_grad_pre(ga[j] * xh + be[j], act, slope);
+      const float g = dv[j] * act_grad_pre(fmaf(ga[j], xh, be[j]), act, slope);
       o[j] = ga[j] * rs[j] * (g - (k0[j] + xh * k1[j]));
     }
     if (dx) *reinterpret_cast<vp_f32x4*>(dx + off) = o;
@@ -445,7 +455,7 @@ int vp_bn_stats_f32(const float* x, int R, int C, float eps, float momentum, flo
   int rc = check_launch("vp_bn_stats_f32(partial)");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, s, (const float*)part, g.chunks_r, R, C, eps,
-                     momentum, mean, rstd, running_mean, running_var);
+                     momentum, mean, rstd, running_mean, running_var, x);
   return check_launch("vp_bn_stats_f32(final)");
 }
 
@@ -538,7 +548,7 @@ int vp_instnorm_act_fwd_f32(const float* x, float* y, float* mean, float* rstd, 
   int rc = check_launch("vp_instnorm_act_fwd_f32(partial)");
   if (rc) return rc;
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_C - 1) / FIN_C, 1, B), dim3(256), 0, s, (const float*)part, g.chunks_r, R, C,
-                     eps, 0.f, mean, rstd, (float*)nullptr, (float*)nullptr, bps);
+                     eps, 0.f, mean, rstd, (float*)nullptr, (float*)nullptr, x, bps, bxs);
   rc = check_launch("vp_instnorm_act_fwd_f32(final)");
   if (rc) return rc;
   if (C % 4 == 0) {

@@ -297,20 +297,32 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
     if (base + i < per) dw[base + i] = tile[i];
 }
 
-// Few outputs, many slabs (the narrow kernels above: one slab per workgroup): 64 outputs x 4 split-lanes per workgroup.
+// Few outputs, many slabs (the narrow kernels above: one slab per workgroup, ~1000 slabs for 4800 outputs): 16 outputs x 16
+// split-lanes per workgroup, four loads in flight per lane, lanes combined through LDS in a fixed order.  (64 outputs x 4
+// lanes left 75 workgroups walking 256 dependent loads each: 34 us for 20 MB.)
 __global__ void __launch_bounds__(256) slab_reduce_deep_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cs, int Cb,
                                                                int nsplit, int nt) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][17];
   const size_t per = (size_t)nt * Cs * Cb;
-  const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int sl = threadIdx.x >> 6;
-  float s = 0.f;
-  if (i < per)
-    for (int sp = sl; sp < nsplit; sp += 4) s += slab[(size_t)sp * per + i];
-  red[sl][threadIdx.x & 63] = s;
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < per) {
+    int sp = sl;
+    for (; sp + 48 < nsplit; sp += 64) {
+      s0 += slab[(size_t)sp * per + i];
+      s1 += slab[(size_t)(sp + 16) * per + i];
+      s2 += slab[(size_t)(sp + 32) * per + i];
+      s3 += slab[(size_t)(sp + 48) * per + i];
+    }
+    for (; sp < nsplit; sp += 16) s0 += slab[(size_t)sp * per + i];
+  }
+  red[sl][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sl == 0 && i < per) {
-    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][o];
     const int cb = (int)(i % Cb);
     const size_t r = i / Cb;
     const int cs = (int)(r % Cs), t = (int)(r / Cs);
@@ -379,7 +391,7 @@ int narrow_wgrad_launch(const float* big, const float* small, float* dw_ref, con
   int rc = check_launch("wgrad_narrow");
   if (rc) return rc;
   const size_t per = (size_t)kTaps * g.Cs * g.Cb;
-  hipLaunchKernelGGL(slab_reduce_deep_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, (const float*)ws, dw_ref, g.Cs, g.Cb, nblk, kTaps);
+  hipLaunchKernelGGL(slab_reduce_deep_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, s, (const float*)ws, dw_ref, g.Cs, g.Cb, nblk, kTaps);
   return check_launch("slab_reduce");
 }
 
@@ -388,7 +400,7 @@ int slab_reduce_launch(const float* slab, float* dw_ref, int Cs, int Cb, int nsp
   if (cc >= 4096 && nt <= 25)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((cc + 63) / 64)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);
   else
-    hipLaunchKernelGGL(slab_reduce_deep_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);
+    hipLaunchKernelGGL(slab_reduce_deep_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);
   return check_launch("slab_reduce");
 }
 

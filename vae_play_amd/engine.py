@@ -505,8 +505,7 @@ class FusedVAEStep:
         (eager mode only)."""
         if not hasattr(self, "_loss_num"):
             self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
-        self.x_nchw.copy_(x, non_blocking=True)
-        self.eps.copy_(eps, non_blocking=True)
+        self._bind_inputs(x, eps)
         if self._graph is not None and timers is None and on_decoder_grads is None and on_dense_grads is None \
                 and on_fc_wgrad is None and after_forward is None:
             self._graph.replay()
@@ -515,6 +514,31 @@ class FusedVAEStep:
         # BatchNorm num_batches_tracked is advanced lazily in sync_counters()
         self._steps_since_sync = getattr(self, "_steps_since_sync", 0) + 1
         return self._loss_num / self.B, self.recon, self.kl_sum
+
+    def _bind_inputs(self, x: torch.Tensor, eps: torch.Tensor) -> None:
+        """Point the launches that consume the batch at the caller's tensors (fp32, contiguous, on this device, right shape:
+        the three-channel transpose reads ``x``, the two latent kernels read ``eps``); anything else -- and the hipGraph
+        replay, whose node arguments are frozen -- is copied into the plan's static buffers."""
+        if not hasattr(self, "_in_slots"):
+            self._in_slots = {"x": [], "eps": []}
+            statics = {"x": self.x_nchw.data_ptr(), "eps": self.eps.data_ptr()}
+            if self.C != 1:                  # one channel: x_nchw doubles as the NHWC activation of the whole plan
+                for plan in (self._fwd, self._bwd_dec, self._bwd_a, self._bwd_b):
+                    for call in plan.calls:
+                        for i, a in enumerate(call[2]):
+                            if isinstance(a, c_void_p):
+                                for k, v in statics.items():
+                                    if a.value == v:
+                                        self._in_slots[k].append((call[2], i))
+        for key, t, static in (("x", x, self.x_nchw), ("eps", eps, self.eps)):
+            slots = self._in_slots[key]
+            direct = (bool(slots) and self._graph is None and t.device == static.device and t.dtype == torch.float32
+                      and t.is_contiguous() and t.shape == static.shape)
+            if not direct:
+                static.copy_(t, non_blocking=True)
+                t = static
+            for args, i in slots:
+                args[i] = c_void_p(t.data_ptr())
 
     def sync_counters(self):
         """Advance BatchNorm ``num_batches_tracked`` buffers (bookkeeping only; kept off the hot path)."""
@@ -610,6 +634,7 @@ class FusedVAEStep:
         """Capture forward+backward into a hipGraph (torch.cuda.CUDAGraph) and replay it from then on."""
         if not hasattr(self, "_loss_num"):
             self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
+        self._bind_inputs(self.x_nchw, self.eps)      # the graph's nodes must read the static buffers
         # warm-up and capture execute the step: keep the BatchNorm running buffers unchanged by them
         saved = [(m, m.running_mean.clone(), m.running_var.clone()) for m in self._bn_mods]
         side = torch.cuda.Stream()
