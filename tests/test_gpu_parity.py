@@ -76,7 +76,9 @@ def test_conv5_gather_scatter_wgrad(B, Hs, Cb, Cs, stride):
                                    (32, 32768, 128), (256, 512, 384),
                                    # skinny kernels (batch-sized M, weights streamed once): ragged M, N off the 128-column
                                    # block, odd tile counts per wave, split and unsplit K
-                                   (7, 200, 320), (32, 132, 4096), (1, 1000, 192), (31, 4100, 64), (16, 256, 8192), (9, 320, 200), (3, 448, 132)])
+                                   (7, 200, 320), (32, 132, 4096), (1, 1000, 192), (31, 4100, 64), (16, 256, 8192), (9, 320, 200), (3, 448, 132),
+                                   # two blocks of 32 batch rows
+                                   (64, 512, 4096), (48, 1024, 256), (33, 260, 192), (64, 256, 8192)])
 def test_linear_forms(M, N, K):
     from vae_play_amd import ops
     g = torch.Generator().manual_seed(M + N + K)

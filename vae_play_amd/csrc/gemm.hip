@@ -83,7 +83,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Skinny dense layers: M <= 32 rows (the batch) against a weight matrix that is read exactly once -- HBM-bound.
+// Skinny dense layers: M <= 64 rows (the batch) against a weight matrix that is read exactly once -- HBM-bound.
 // The general tile kernel stages BOTH operands through LDS with two barriers per K-tile and reached 2-3 TB/s on the
 // 134 MB encoder.fc.0 matrix.  Here the weights go straight from global memory into the MFMA B operand (each element
 // is used by one wave only, so LDS buys nothing), eight 16-B loads in flight per lane, and only the activation rows
@@ -94,11 +94,13 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
 constexpr int SK_KT = 64;   // k per tile
 
 // mode 0 (Linear forward): A[m][k] and B[n][k] both k-contiguous.  Workgroup = 4 waves x 32 columns; the A tile
-// [32][64] is shared through LDS (two buffers, one barrier per tile).  grid = (ceil(N/128), nsplit).
+// [32 TM][64] is shared through LDS (two buffers, one barrier per tile).  TM = 1 | 2 blocks of 32 batch rows: a weight
+// fragment feeds TM MFMAs.  grid = (ceil(N/128), nsplit).
+template <int TM>
 __global__ void __launch_bounds__(256) skinny_mk_kernel(const float* __restrict__ A, long sam, const float* __restrict__ Bm, long sbn,
                                                         float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
                                                         int K, int nsplit, int kps) {
-  __shared__ __attribute__((aligned(16))) float xs[2][32][SK_KT + 4];
+  __shared__ __attribute__((aligned(16))) float xs[2][32 * TM][SK_KT + 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int n = blockIdx.x * 128 + wave * 32 + li;
@@ -107,21 +109,34 @@ __global__ void __launch_bounds__(256) skinny_mk_kernel(const float* __restrict_
   const int k_end = min(K, k_begin + kps);
   const int nk = (k_end - k_begin) / SK_KT;
   const int xrow = tid >> 3, xc = tid & 7;
-  const float* arow = A + (size_t)(xrow < M ? xrow : 0) * sam;
-  const bool xok = xrow < M;
-  vp_f32x4 xr0, xr1, w[8], wn[8];
-  f32x16 acc;
+  const float* arow[TM];
+  bool xok[TM];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int b = 0; b < TM; ++b) {
+    xok[b] = xrow + 32 * b < M;
+    arow[b] = A + (size_t)(xok[b] ? xrow + 32 * b : 0) * sam;
+  }
+  vp_f32x4 xr[TM][2], w[8], wn[8];
+  f32x16 acc[TM];
+#pragma unroll
+  for (int b = 0; b < TM; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
   auto load_tile = [&](int kb) {
-    xr0 = xok ? ld4(arow + kb + xc * 4) : zero4();
-    xr1 = xok ? ld4(arow + kb + 32 + xc * 4) : zero4();
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      xr[b][0] = xok[b] ? ld4(arow[b] + kb + xc * 4) : zero4();
+      xr[b][1] = xok[b] ? ld4(arow[b] + kb + 32 + xc * 4) : zero4();
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) wn[i] = ld4(wrow + kb + lh * 32 + i * 4);   // one 128-B line per lane and tile
   };
   auto write_x = [&](int buf) {
-    *reinterpret_cast<vp_f32x4*>(&xs[buf][xrow][xc * 4]) = xr0;
-    *reinterpret_cast<vp_f32x4*>(&xs[buf][xrow][32 + xc * 4]) = xr1;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      *reinterpret_cast<vp_f32x4*>(&xs[buf][xrow + 32 * b][xc * 4]) = xr[b][0];
+      *reinterpret_cast<vp_f32x4*>(&xs[buf][xrow + 32 * b][32 + xc * 4]) = xr[b][1];
+    }
   };
   if (nk > 0) {
     load_tile(k_begin);
@@ -136,113 +151,137 @@ __global__ void __launch_bounds__(256) skinny_mk_kernel(const float* __restrict_
     const int cur = t & 1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const vp_f32x4 x4 = *reinterpret_cast<const vp_f32x4*>(&xs[cur][li][lh * 32 + i * 4]);
+      vp_f32x4 x4[TM];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[j], w[i][j], acc, 0, 0, 0);
+      for (int b = 0; b < TM; ++b) x4[b] = *reinterpret_cast<const vp_f32x4*>(&xs[cur][li + 32 * b][lh * 32 + i * 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[b][j], w[i][j], acc[b], 0, 0, 0);
     }
     if (more) write_x(cur ^ 1);      // last read in iteration t-1, which every wave left through the barrier below
     __syncthreads();
   }
   if (n >= N) return;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (m >= M) continue;
-    if (nsplit == 1) C[(size_t)m * ldc + n] = acc[r] + (bias ? bias[n] : 0.f);
-    else C[((size_t)blockIdx.y * M + m) * N + n] = acc[r];
-  }
+  for (int b = 0; b < TM; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+      if (nsplit == 1) C[(size_t)m * ldc + n] = acc[b][r] + (bias ? bias[n] : 0.f);
+      else C[((size_t)blockIdx.y * M + m) * N + n] = acc[b][r];
+    }
 }
 
 // mode 1 (Linear input gradient): A[m][k] k-contiguous, B[k][n] n-contiguous.  A lane's 16-B weight load covers 4 columns of
-// one k row, so a wave owns 128 columns (4 accumulators) and reuses its A value four times; the 4 waves of a workgroup take
-// interleaved 64-deep k tiles of the workgroup's K range and are summed through LDS in a fixed order at the end.  No barrier
-// in the main loop: the A values (L2-resident) are loaded per lane as well.  grid = (ceil(N/128), nsplit).
+// one k row, so a wave owns 128 columns (4 accumulators per 32 batch rows) and reuses its A value four times; the 4 waves of a
+// workgroup take interleaved 64-deep k tiles of the workgroup's K range and are summed through LDS in a fixed order at the
+// end.  No barrier in the main loop: the A values (L2-resident) are loaded per lane as well.  grid = (ceil(N/128), nsplit).
+template <int TM>
 __global__ void __launch_bounds__(256) skinny_kn_kernel(const float* __restrict__ A, long sam, const float* __restrict__ Bm, long sbk,
                                                         float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
                                                         int K, int nsplit, int kps) {
-  __shared__ __attribute__((aligned(16))) float red[2][64][64];   // [wave slot][register][lane]
+  __shared__ __attribute__((aligned(16))) float red[2][64][64];   // [wave slot][register][lane], one 32-row block at a time
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 128 + 4 * li;           // this lane's 4 columns (N % 4 == 0)
   const bool nok = n0 < N;
   const float* wcol = Bm + (nok ? n0 : 0);
-  const float* arow = A + (size_t)(li < M ? li : 0) * sam;
-  const bool aok = li < M;
+  const float* arow[TM];
+  bool aok[TM];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    aok[b] = li + 32 * b < M;
+    arow[b] = A + (size_t)(aok[b] ? li + 32 * b : 0) * sam;
+  }
   const int k_begin = blockIdx.y * kps;
   const int k_end = min(K, k_begin + kps);
   const int nk = (k_end - k_begin) / SK_KT;          // tiles of the workgroup; wave w takes tiles w, w+4, ...
-  f32x16 acc[4];
+  f32x16 acc[TM][4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int b = 0; b < TM; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  vp_f32x4 w[8], wn[8], a[2], an[2];
-  // half a tile (32 k) per step: q = 0..3 blocks of 8 k; lane half h, step j <-> k = kb + 8 q + 4 h + j
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][c][r] = 0.f;
+  vp_f32x4 w[8], wn[8], a[TM][2], an[TM][2];
+  // 16 k rows per step: q = 0..1 blocks of 8 k; lane half h, step j <-> k = kb + 8 q + 4 h + j
   auto load_half = [&](int kb) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      an[q] = aok ? ld4(arow + kb + q * 8 + lh * 4) : zero4();
+#pragma unroll
+      for (int b = 0; b < TM; ++b) an[b][q] = aok[b] ? ld4(arow[b] + kb + q * 8 + lh * 4) : zero4();
 #pragma unroll
       for (int j = 0; j < 4; ++j) wn[q * 4 + j] = ld4(wcol + (size_t)(kb + q * 8 + lh * 4 + j) * sbk);
     }
   };
-  const int nh = nk > wave ? ((nk - wave + 3) / 4) * 4 : 0;   // 16-k-row steps of this wave: 4 per tile
+  const int nh = nk > wave ? ((nk - wave + 3) / 4) * 4 : 0;   // steps of this wave: 4 per tile
   auto kb_of = [&](int h) { return k_begin + (wave + 4 * (h >> 2)) * SK_KT + (h & 3) * 16; };
   if (nh > 0) load_half(kb_of(0));
   for (int h = 0; h < nh; ++h) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = wn[i];
-    a[0] = an[0]; a[1] = an[1];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) { a[b][0] = an[b][0]; a[b][1] = an[b][1]; }
     if (h + 1 < nh) load_half(kb_of(h + 1));
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], w[q * 4 + j][c], acc[c], 0, 0, 0);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+            acc[b][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][q][j], w[q * 4 + j][c], acc[b][c], 0, 0, 0);
   }
-  // (wave 2, wave 3) -> LDS, added by (wave 0, wave 1); then wave 1 -> LDS, added by wave 0
-  if (wave >= 2) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+  for (int b = 0; b < TM; ++b) {
+    // (wave 2, wave 3) -> LDS, added by (wave 0, wave 1); then wave 1 -> LDS, added by wave 0
+    __syncthreads();
+    if (wave >= 2) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave - 2][c * 16 + r][lane] = acc[c][r];
-  }
-  __syncthreads();
-  if (wave < 2) {
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 16; ++r) red[wave - 2][c * 16 + r][lane] = acc[b][c][r];
+    }
+    __syncthreads();
+    if (wave < 2) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] += red[wave][c * 16 + r][lane];
-  }
-  __syncthreads();
-  if (wave == 1) {
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 16; ++r) acc[b][c][r] += red[wave][c * 16 + r][lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[0][c * 16 + r][lane] = acc[c][r];
-  }
-  __syncthreads();
-  if (wave != 0 || !nok) return;
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (m >= M) continue;
-    vp_f32x4 v;
+        for (int r = 0; r < 16; ++r) red[0][c * 16 + r][lane] = acc[b][c][r];
+    }
+    __syncthreads();
+    if (wave == 0 && nok) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = acc[c][r] + red[0][c * 16 + r][lane];
-    if (nsplit == 1) {
-      if (bias) { v[0] += bias[n0]; v[1] += bias[n0 + 1]; v[2] += bias[n0 + 2]; v[3] += bias[n0 + 3]; }
-      *reinterpret_cast<vp_f32x4*>(C + (size_t)m * ldc + n0) = v;
-    } else {
-      *reinterpret_cast<vp_f32x4*>(C + ((size_t)blockIdx.y * M + m) * N + n0) = v;
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= M) continue;
+        vp_f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = acc[b][c][r] + red[0][c * 16 + r][lane];
+        if (nsplit == 1) {
+          if (bias) { v[0] += bias[n0]; v[1] += bias[n0 + 1]; v[2] += bias[n0 + 2]; v[3] += bias[n0 + 3]; }
+          *reinterpret_cast<vp_f32x4*>(C + (size_t)m * ldc + n0) = v;
+        } else {
+          *reinterpret_cast<vp_f32x4*>(C + ((size_t)blockIdx.y * M + m) * N + n0) = v;
+        }
+      }
     }
   }
 }
 
 // Split count of the skinny kernels (0: shape not eligible).  mode 0 / 1 as in vp_gemm_f32.
 inline int skinny_nsplit(int mode, long M, long N, long K) {
-  if (mode > 1 || M > 32 || N < 128 || K % SK_KT) return 0;
+  if (mode > 1 || M > 64 || N < 128 || K % SK_KT) return 0;
   if (const char* e = getenv("VP_GEMM_SKINNY")) if (atoi(e) == 0) return 0;   // A/B knob
   const long colblocks = (N + 127) / 128;
   const long unit = mode == 0 ? 256 : 4 * SK_KT;      // smallest K range worth a workgroup
@@ -301,8 +340,10 @@ int vp_gemm_f32(const float* A, long sam, long sak, const float* B, long sbn, lo
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)ns);
-    if (mode == 0) hipLaunchKernelGGL(skinny_mk_kernel, grid, dim3(256), 0, s, A, sam, B, sbn, dst, ldc, bias, M, N, K, ns, kps);
-    else hipLaunchKernelGGL(skinny_kn_kernel, grid, dim3(256), 0, s, A, sam, B, sbk, dst, ldc, bias, M, N, K, ns, kps);
+    if (mode == 0 && M <= 32) hipLaunchKernelGGL(skinny_mk_kernel<1>, grid, dim3(256), 0, s, A, sam, B, sbn, dst, ldc, bias, M, N, K, ns, kps);
+    else if (mode == 0) hipLaunchKernelGGL(skinny_mk_kernel<2>, grid, dim3(256), 0, s, A, sam, B, sbn, dst, ldc, bias, M, N, K, ns, kps);
+    else if (M <= 32) hipLaunchKernelGGL(skinny_kn_kernel<1>, grid, dim3(256), 0, s, A, sam, B, sbk, dst, ldc, bias, M, N, K, ns, kps);
+    else hipLaunchKernelGGL(skinny_kn_kernel<2>, grid, dim3(256), 0, s, A, sam, B, sbk, dst, ldc, bias, M, N, K, ns, kps);
     int rc = check_launch("vp_gemm_f32(skinny)");
     if (rc || ns == 1) return rc;
     if (ns >= 16 && (size_t)M * N <= 65536)
