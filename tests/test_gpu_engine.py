@@ -177,3 +177,33 @@ def test_concurrent_schedule_is_bit_identical_to_the_serial_one(monkeypatch):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     for u, v in zip(a[3], b[3]):
         assert torch.equal(u, v)
+
+
+def test_fused_step_binds_or_copies_the_callers_batch():
+    """The launches that consume the batch read the caller's tensors in place when they are fp32, contiguous and on the
+    device; anything else (a strided view, fp64 data, a host tensor) is copied into the plan's static buffers.  All
+    forms must give the same numbers, and a second call with OTHER tensors must not see the first call's data."""
+    from oracle import ref_cpu as O
+    C, S, z, B = 3, 32, 16, 8
+    vae, opt, fused, p0, L = build(C, S, z, B, precision="f32")
+    x, eps = O.synthetic_batch(B, C, S, z)
+    xd, epsd = x.to(DEV), eps.to(DEV)
+    loss0, _, _ = fused.forward_backward(xd, epsd)
+    g0 = opt.flat_grad.clone()
+    wide = torch.zeros(B, C, S, 2 * S, device=DEV)
+    wide[..., ::2] = xd
+    used = torch.zeros_like(g0, dtype=torch.bool)          # alignment padding of the arena is never written
+    for p, o in zip(opt.arena.params, opt.arena.offsets):
+        used[o:o + p.numel()] = True
+    forms = {"strided view": (wide[..., ::2], epsd), "fp64": (xd.double(), epsd.double()), "host tensors": (x, eps),
+             "fresh device copies": (xd.clone(), epsd.clone())}
+    for tag, (xi, ei) in forms.items():
+        opt.flat_grad.fill_(float("nan"))
+        li, _, _ = fused.forward_backward(xi, ei)
+        assert li.item() == loss0.item(), tag
+        assert torch.equal(opt.flat_grad[used], g0[used]), tag
+    x2, eps2 = torch.rand_like(xd), torch.randn_like(epsd)
+    l2, _, _ = fused.forward_backward(x2, eps2)
+    assert l2.item() != loss0.item()
+    l3, _, _ = fused.forward_backward(xd, epsd)
+    assert l3.item() == loss0.item()
