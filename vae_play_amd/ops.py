@@ -441,6 +441,16 @@ def pack_w5_split(w_ref: torch.Tensor, want_p0: bool, want_p1: bool):
     return p0, p1
 
 
+def pack_w5_p1_split_padded(w_ref: torch.Tensor, cs_pad: int = 8) -> torch.Tensor:
+    """Packed P1 split planes [Cbig][25][cs_pad] of a conv whose small side has 1 or 3 channels, zero-padded to ``cs_pad``
+    (the narrow side of the final conv, models/networks.py:100-103): its input gradient then runs on the MFMA kernels."""
+    Cs, Cb = w_ref.shape[0], w_ref.shape[1]
+    w_ref = w_ref.contiguous()
+    out = empty_split(Cb * 25 * cs_pad, w_ref)
+    _lib.call("vp_pack_w5_p1_split_padded", _p(w_ref), _pv(out), Cs, Cb, cs_pad, _stream())
+    return out
+
+
 def conv5_gather_bf16x3(big_split, shape_big, w_p0_split, Cs: int, bias, stride: int, act: int = ACT_NONE):
     B, Cb, Hb, Wb = shape_big
     Hs, Ws = Hb // stride, Wb // stride
