@@ -96,6 +96,9 @@ int vp_conv_wgrad_bf16x3(const void* big_split, const void* small_split, float* 
  * ~5e-6 relative error per contraction.  Channel counts on the contracted/vector side must be
  * multiples of 8; outputs are plain fp32.  Same reference lines as the f32 entry points above. */
 int vp_split_f32(const float* x, void* out_split, size_t n, vp_stream stream);
+/* the same for an NHWC tensor [npix][C] whose channel count is not a multiple of 8: planes [npix][Cpad], channels C..Cpad-1
+ * zero (models/blocks.py:97-146 AddCoords makes 32 + 2 channels; the heads of models/networks_BE.py:39-89 end in 1 channel) */
+int vp_split_pad_f32(const float* x, void* out_split, size_t npix, int C, int Cpad, vp_stream stream);
 int vp_pack_w5_split(const float* w_ref, void* p0_split, void* p1_split, int Csmall, int Cbig, vp_stream stream);
 int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const float* bias, float* small_out,
                            int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream);

@@ -109,3 +109,36 @@ def test_bf16x3_kxk_families(B, Hb, Wb, Cb, Cs, ks, stride):
     assert_close(dx, bigr.grad, X3_RTOL, "k x k scatter bf16x3")
     dw = ops.conv_wgrad_bf16x3(big_s, big.shape, small_s, small.shape, ks, stride)
     assert_close(dw, wr.grad, X3_RTOL, "k x k wgrad bf16x3")
+
+
+PADDED = [  # (B, H, W, Cin, Cout, ks, stride): channel counts that are NOT multiples of 8 (coordinate channels, 1-2 outputs, RGB in)
+    (2, 16, 16, 34, 32, 3, 1), (2, 16, 16, 32, 1, 3, 1), (2, 17, 13, 3, 16, 5, 2), (1, 12, 12, 34, 2, 1, 1), (2, 10, 10, 66, 12, 3, 2), (2, 16, 16, 2, 1, 3, 1), (1, 9, 11, 1, 1, 3, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,ks,stride", PADDED)
+def test_conv2d_bf16x3_mode_with_padded_channels(B, H, W, Ci, Co, ks, stride):
+    """functional.conv2d under set_conv_precision("bf16x3") zero-pads such channel counts to the next multiple of 8 and stays
+    on the split-bf16 kernels: output, input gradient, weight gradient and bias gradient against torch (fp32)."""
+    import vae_play_amd as V
+    from vae_play_amd import functional as FH
+    g = torch.Generator().manual_seed(B + H + Ci + Co + ks)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, ks, ks, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y = F.conv2d(xr, wr, br, stride=stride, padding=(ks - 1) // 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    V.set_conv_precision("bf16x3")
+    try:
+        yd = FH.conv2d(xd, wd, bd, stride)
+        yd.backward(gy.to(DEV))
+    finally:
+        V.set_conv_precision("f32")
+    assert tuple(yd.shape) == tuple(y.shape)
+    assert_close(yd, y.detach(), X3_RTOL, "padded conv y")
+    assert_close(xd.grad, xr.grad, X3_RTOL, "padded conv dx")
+    assert_close(wd.grad, wr.grad, X3_RTOL, "padded conv dw")
+    assert_close(bd.grad, br.grad, X3_RTOL, "padded conv db")

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vp_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 9),
     "vp_conv_wgrad_f32": (c_int, [P, P, P] + [c_int] * 9 + [P, c_size_t, P]),
     "vp_split_f32": (c_int, [P, P, c_size_t, P]),
+    "vp_split_pad_f32": (c_int, [P, P, c_size_t, c_int, c_int, P]),
     "vp_pack_w5_split": (c_int, [P, P, P, c_int, c_int, P]),
     "vp_pack_w_split": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "vp_conv_gather_bf16x3": (c_int, [P, P, P, P] + [c_int] * 10 + [P]),

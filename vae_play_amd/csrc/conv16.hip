@@ -22,6 +22,21 @@ __global__ void split_kernel(const float* __restrict__ x, u16_t* __restrict__ ou
   }
 }
 
+// [npix][C] fp32 -> split planes [npix][Cpad] with zero channels C..Cpad-1 (Cpad a multiple of 8): lets a layer whose channel
+// count is not a multiple of 8 (1 or 2 outputs, 32 + 2 coordinate channels, models/blocks.py:97-146) use the split-bf16 kernels.
+__global__ void split_pad_kernel(const float* __restrict__ x, u16_t* __restrict__ out, size_t npix, int C, int Cpad) {
+  const size_t n = npix * (size_t)Cpad, n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4, pix = e / Cpad;
+    const int c = (int)(e - pix * Cpad);            // Cpad % 4 == 0: the four elements share a pixel
+    const float* src = x + pix * (size_t)C;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = c + j < C ? src[c + j] : 0.f;
+    store_split4(out, n, e, v[0], v[1], v[2], v[3]);
+  }
+}
+
 // Weight re-pack through LDS so that both the fp32 reads and the packed writes are contiguous.
 //   MODE 0: p0[cs][t][cb] <- w[cs][cb][t]   (one cs, 64 cb per workgroup: 1600 contiguous floats in)
 //   MODE 1: p1[cb][t][cs] <- w[cs][cb][t]   (one cb, 64 cs per workgroup: 64 x 100-B segments in)
@@ -214,6 +229,13 @@ int vp_split_f32(const float* x, void* out_split, size_t n, vp_stream stream) {
   VP_REQUIRE((n & 3) == 0 || true, "unreachable");
   hipLaunchKernelGGL(split_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, (u16_t*)out_split, n);
   return check_launch("vp_split_f32");
+}
+
+int vp_split_pad_f32(const float* x, void* out_split, size_t npix, int C, int Cpad, vp_stream stream) {
+  VP_REQUIRE(x && out_split && npix > 0 && C > 0 && Cpad >= C && Cpad % 8 == 0, "vp_split_pad_f32: Cpad must be a multiple of 8 and >= C");
+  hipLaunchKernelGGL(split_pad_kernel, dim3(grid_for(npix * (size_t)Cpad / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (u16_t*)out_split, npix, C, Cpad);
+  return check_launch("vp_split_pad_f32");
 }
 
 int vp_pack_w5_split(const float* w_ref, void* p0_split, void* p1_split, int Csmall, int Cbig, vp_stream stream) {

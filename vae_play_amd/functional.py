@@ -234,6 +234,23 @@ class _ConvK(Function):
         ks = weight.shape[2]
         ctx.x16 = _use16(weight)
         ctx.xshape = tuple(x.shape)
+        ctx.pad = None
+        Co, Ci = weight.shape[0], weight.shape[1]
+        if _PRECISION == "bf16x3" and not ctx.x16:
+            # a channel count that is not a multiple of 8 on either side (32 + 2 coordinate channels in, 1 or 2 channels out):
+            # zero-pad it to the next multiple of 8 and stay on the split-bf16 kernels -- the exact-f32 tile kernels run these
+            # shapes with 70-97 % padding of their own (networks_BE heads: 65 % of the step in one f32 weight-gradient kernel)
+            Cop, Cip = (Co + 7) // 8 * 8, (Ci + 7) // 8 * 8
+            wp = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, Cip - Ci, 0, Cop - Co)) if (Cop != Co or Cip != Ci) else weight
+            bp = None if bias is None else (torch.nn.functional.pad(bias, (0, Cop - Co)) if Cop != Co else bias)
+            xs = ops.split_pad(x, Cip) if Cip != Ci else ops.split_f32(x)
+            B, _, H, W = x.shape
+            p0, _ = ops.pack_w_split(wp, True, False)
+            y = ops.conv_gather_bf16x3(xs, (B, Cip, H, W), p0, Cop, bp, ks, stride, ACT_NONE)
+            ctx.pad = (Co, Ci, Cop, Cip)
+            ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
+            ctx.save_for_backward(xs, weight)
+            return y[:, :Co] if Cop != Co else y
         if ctx.x16:                     # split-bf16 kernels (set_conv_precision("bf16x3"), channel counts multiples of 8)
             xs = ops.split_f32(x)
             p0, _ = ops.pack_w_split(weight, True, False)
@@ -251,6 +268,21 @@ class _ConvK(Function):
         x, weight = ctx.saved_tensors
         dy = _cl(dy)
         dx = dw = db = None
+        if ctx.pad is not None:
+            Co, Ci, Cop, Cip = ctx.pad
+            B, _, Ho, Wo = dy.shape
+            dys = ops.split_pad(dy, Cop) if Cop != Co else ops.split_f32(dy)
+            if ctx.needs_input_grad[0]:
+                wp = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, Cip - Ci, 0, Cop - Co)) if (Cop != Co or Cip != Ci) else weight
+                _, p1 = ops.pack_w_split(wp, False, True)
+                dx = ops.conv_scatter_bf16x3(dys, (B, Cop, Ho, Wo), p1, Cip, ctx.ks, ctx.stride, ctx.xshape[2], ctx.xshape[3])
+                dx = dx[:, :Ci] if Cip != Ci else dx
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv_wgrad_bf16x3(x, (B, Cip, ctx.xshape[2], ctx.xshape[3]), dys, (B, Cop, Ho, Wo), ctx.ks, ctx.stride)
+                dw = dw[:Co, :Ci].contiguous() if (Cop != Co or Cip != Ci) else dw
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))
+            return dx, dw, db, None
         if ctx.x16:
             dys = ops.split_f32(dy)
             if ctx.needs_input_grad[0]:

@@ -426,6 +426,15 @@ def split_f32(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_pad(x: torch.Tensor, cpad: int) -> torch.Tensor:
+    """Split planes of an NHWC activation (logical (B, C, H, W), channels_last) with the channels zero-padded to ``cpad``."""
+    B, C, H, W = x.shape
+    x = x if _is_nhwc(x) else x.contiguous(memory_format=torch.channels_last)
+    out = empty_split(B * H * W * cpad, x)
+    _lib.call("vp_split_pad_f32", _p(x), _pv(out), B * H * W, C, cpad, _stream())
+    return out
+
+
 def unsplit(s: torch.Tensor) -> torch.Tensor:
     """hi + lo as fp32 (test helper; torch ops)."""
     return s[0].view(torch.bfloat16).float() + s[1].view(torch.bfloat16).float()
