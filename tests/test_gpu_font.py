@@ -14,6 +14,17 @@ def dev(x):
     return x.to(DEV)
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_precision(request):
+    """Both arithmetic modes of the k x k convolutions: exact-fp32 MFMA and split-bf16 (the mode the benches of this row
+    report; channel counts that are not multiples of 8 are zero-padded into the split planes)."""
+    import vae_play_amd as V
+    V.set_conv_precision(request.param)
+    yield request.param
+    V.set_conv_precision("f32")
+
+
+
 def dev_y(y):
     return {k: v.to(DEV) for k, v in y.items()}
 
@@ -82,7 +93,7 @@ def test_self_attention_block_matches_oracle(hw):
             assert_close(q.grad, ref, 1e-4, f"attention grad {n}")
 
 
-def test_compose_net_against_reference_golden():
+def test_compose_net_against_reference_golden(conv_precision):
     from oracle import ref_font as FN
     import vae_play_amd.networks_BE_font as N
     g = load_golden("font_compose16_b2")
@@ -99,12 +110,15 @@ def test_compose_net_against_reference_golden():
         ((out["masks"] * dev(t(g[f"{branch}/gm"]))).sum() + (out["edges"] * dev(t(g[f"{branch}/ge"]))).sum()).backward()
         for n, p in net.named_parameters():
             if f"{branch}/grad/{n}/l2" in g:
-                check_sampled(f"{branch} grad {n}", p.grad, g, f"{branch}/grad/{n}", NORTH_STAR_RTOL * 5)
+                # font_compose16_b2 is a 16 x 16, batch-2 fixture: its one-element attention gammas sum a handful of products and
+                # moved by up to 2.7e-2 under the split-bf16 contraction noise (5e-6 per op), everything else stays inside 5e-3
+                tol = 5e-2 if (conv_precision == "bf16x3" and p.numel() == 1) else NORTH_STAR_RTOL * 5
+                check_sampled(f"{branch} grad {n}", p.grad, g, f"{branch}/grad/{n}", tol)
             else:
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{branch}: unexpected gradient for {n}"
 
 
-def test_discriminator_against_reference_golden():
+def test_discriminator_against_reference_golden(conv_precision):
     from oracle import ref_font as FN
     import vae_play_amd.networks_BE_font as N
     g = load_golden("font_disc32_b2")
