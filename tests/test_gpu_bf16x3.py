@@ -142,3 +142,32 @@ def test_conv2d_bf16x3_mode_with_padded_channels(B, H, W, Ci, Co, ks, stride):
     assert_close(xd.grad, xr.grad, X3_RTOL, "padded conv dx")
     assert_close(wd.grad, wr.grad, X3_RTOL, "padded conv dw")
     assert_close(bd.grad, br.grad, X3_RTOL, "padded conv db")
+
+
+def test_bn_act_output_carries_its_split_planes_in_bf16x3_mode():
+    """In bf16x3 mode BatchNorm+activation emits the bf16 hi/lo planes of its output in the same pass and the next
+    convolution picks them up instead of running a split pass: the planes must equal split_f32(y), survive Function.apply,
+    and be ignored once y is written in place."""
+    import vae_play_amd as V
+    from vae_play_amd import functional as FH, ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 16, 12, 12, generator=g).to(DEV).requires_grad_(True)
+    gamma, beta = (torch.rand(16, generator=g) + 0.5).to(DEV).requires_grad_(True), torch.randn(16, generator=g).to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(16, device=DEV), torch.ones(16, device=DEV)
+    w = (torch.randn(8, 16, 3, 3, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    V.set_conv_precision("bf16x3")
+    try:
+        y = FH.batch_norm_act(x, gamma, beta, rm, rv, True, 0.9, 1e-5, "relu", 0.0)
+        assert hasattr(y, "_vp_split"), "the producer's planes did not survive Function.apply"
+        assert torch.equal(y._vp_split[0], ops.split_f32(y.detach()))
+        assert FH._split_of(y) is y._vp_split[0]
+        out = FH.conv2d(y, w, None, 1)
+        ref = F.conv2d(y.detach().cpu(), w.detach().cpu(), None, padding=1)
+        assert_close(out, ref, X3_RTOL, "conv on carried planes")
+        out.sum().backward()
+        y2 = FH.batch_norm_act(x.detach(), gamma.detach(), beta.detach(), rm, rv, True, 0.9, 1e-5, "relu", 0.0)
+        y2.mul_(2.0)                                   # written in place: the carried planes are stale and must not be used
+        assert FH._split_of(y2) is not y2._vp_split[0]
+        assert torch.equal(FH._split_of(y2), ops.split_f32(y2))
+    finally:
+        V.set_conv_precision("f32")

@@ -43,6 +43,15 @@ def get_conv_precision() -> str:
     return _PRECISION
 
 
+def _split_of(x: torch.Tensor) -> torch.Tensor:
+    """bf16 hi/lo planes of an NHWC activation: the copy its producer emitted in the same pass (a BatchNorm+activation
+    output in bf16x3 mode carries one, valid while the tensor has not been written since), else a split pass."""
+    c = getattr(x, "_vp_split", None)
+    if c is not None and c[1] == x._version and c[0].numel() == 2 * x.numel():
+        return c[0]
+    return ops.split_f32(x)
+
+
 def _use16(weight) -> bool:
     return _PRECISION == "bf16x3" and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
 
@@ -55,7 +64,7 @@ class _Conv5(Function):
         x = _cl(x)
         ctx.x16 = _use16(weight) and act in (ACT_NONE, ACT_SIGMOID)
         if ctx.x16:
-            xs = ops.split_f32(x)
+            xs = _split_of(x)
             p0, _ = ops.pack_w5_split(weight, True, False)
             y = ops.conv5_gather_bf16x3(xs, x.shape, p0, weight.shape[0], bias, stride, act)
             ctx.xshape = tuple(x.shape)
@@ -112,7 +121,7 @@ class _ConvT5(Function):
         x = _cl(x)
         ctx.x16 = _use16(weight)
         if ctx.x16:
-            xs = ops.split_f32(x)
+            xs = _split_of(x)
             _, p1 = ops.pack_w5_split(weight, False, True)
             y = ops.conv5_scatter_bf16x3(xs, x.shape, p1, weight.shape[1], stride)
             ctx.xshape = tuple(x.shape)
@@ -158,7 +167,12 @@ class _BatchNormAct(Function):
         else:
             mean = running_mean
             rstd = torch.rsqrt(running_var + eps)
-        y = ops.bn_act_fwd(x, mean, rstd, gamma, beta, act, slope)
+        if _PRECISION == "bf16x3" and x.dim() == 4 and x.shape[1] % 8 == 0:
+            # the consumer is almost always a convolution on the split-bf16 kernels: emit its operand planes from this pass
+            y, ys = ops.bn_act_fwd(x, mean, rstd, gamma, beta, act, slope, want_split=True)
+            y._vp_split = (ys, y._version)
+        else:
+            y = ops.bn_act_fwd(x, mean, rstd, gamma, beta, act, slope)
         ctx.act, ctx.slope, ctx.training = act, slope, training
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         return y
@@ -243,7 +257,7 @@ class _ConvK(Function):
             Cop, Cip = (Co + 7) // 8 * 8, (Ci + 7) // 8 * 8
             wp = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, Cip - Ci, 0, Cop - Co)) if (Cop != Co or Cip != Ci) else weight
             bp = None if bias is None else (torch.nn.functional.pad(bias, (0, Cop - Co)) if Cop != Co else bias)
-            xs = ops.split_pad(x, Cip) if Cip != Ci else ops.split_f32(x)
+            xs = ops.split_pad(x, Cip) if Cip != Ci else _split_of(x)
             B, _, H, W = x.shape
             p0, _ = ops.pack_w_split(wp, True, False)
             y = ops.conv_gather_bf16x3(xs, (B, Cip, H, W), p0, Cop, bp, ks, stride, ACT_NONE)
@@ -252,7 +266,7 @@ class _ConvK(Function):
             ctx.save_for_backward(xs, weight)
             return y[:, :Co] if Cop != Co else y
         if ctx.x16:                     # split-bf16 kernels (set_conv_precision("bf16x3"), channel counts multiples of 8)
-            xs = ops.split_f32(x)
+            xs = _split_of(x)
             p0, _ = ops.pack_w_split(weight, True, False)
             y = ops.conv_gather_bf16x3(xs, x.shape, p0, weight.shape[0], bias, ks, stride, ACT_NONE)
             x = xs

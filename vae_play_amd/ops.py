@@ -194,9 +194,15 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None):
     return mean, rstd
 
 
-def bn_act_fwd(x, mean, rstd, gamma, beta, act: int, slope: float = 0.0):
+def bn_act_fwd(x, mean, rstd, gamma, beta, act: int, slope: float = 0.0, want_split: bool = False):
+    """``want_split``: also emit the bf16 hi/lo planes of y from the same pass (C % 4 == 0); returns (y, y_split)."""
     R, C = _rc(x)
     y = torch.empty_like(x)  # preserves channels_last strides
+    if want_split:
+        ys = empty_split(x.numel(), x)
+        _lib.call("vp_bn_act_fwd_split_f32", _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), _pv(ys), R, C, act, float(slope),
+                  _stream())
+        return y, ys
     _lib.call("vp_bn_act_fwd_f32", _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), R, C, act, float(slope), _stream())
     return y
 
