@@ -1,12 +1,12 @@
 """Decoder alone, loss = mse(x, decoder(z)): gradient w.r.t. every block output and parameter, HIP modules vs the oracle in
-fp64 (and the oracle in fp32 for scale).  usage: python tools/decoder_bwd_diag.py [img] [z] [batch]"""
+fp64 (and the oracle in fp32 for scale).  usage: python tests/diag/decoder_bwd_diag.py [img] [z] [batch]"""
 import os
 import sys
 
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref_cpu as O, ref_vaegan as G  # noqa: E402  (checker only)
 import vae_play_amd as V  # noqa: E402
 

@@ -1,13 +1,13 @@
 """Per-tensor deviation of the VAE-GAN step's accumulated gradients from an fp64 run of the oracle: the oracle in fp32 (the
 reference's own arithmetic noise), and the HIP modules with the skinny dense kernels off / on.
-usage: python tools/vaegan_grad_noise.py [img] [z] [batch]"""
+usage: python tests/diag/vaegan_grad_noise.py [img] [z] [batch]"""
 import os
 import sys
 
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref_cpu as O, ref_vaegan as G  # noqa: E402  (checker only)
 
 S, z, B = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 32, 4)

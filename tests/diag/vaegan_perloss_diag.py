@@ -1,12 +1,12 @@
 """Relative L2 error of every per-loss gradient of the VAE-GAN step (HIP modules vs the oracle in fp64 on CPU).
-usage: python tools/vaegan_perloss_diag.py [img] [z] [batch]"""
+usage: python tests/diag/vaegan_perloss_diag.py [img] [z] [batch]"""
 import os
 import sys
 
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref_cpu as O, ref_vaegan as G  # noqa: E402  (checker only)
 import vae_play_amd as V  # noqa: E402
 

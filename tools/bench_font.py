@@ -28,8 +28,6 @@ def main():
     import vae_play_amd.networks_BE_font as N
     from vae_play_amd import functional as Fh
     from vae_play_amd import optim, parallel
-    from oracle import ref_cpu as O
-    from oracle import ref_font as FN
     # one process per GPU under torchrun (BASELINE config 5: 8 x MI355X): --batch images PER RANK; every phase all-reduces
     # (averages) the gradients it is about to apply; VP_BENCH_BACKEND=gloo rehearses it with several ranks on one GPU
     rank, world, local = parallel.init_from_env(os.environ.get("VP_BENCH_BACKEND"))
@@ -52,7 +50,15 @@ def main():
         else:
             o.step()
 
-    imgs, masks, edges, labels, y = FN.synthetic_batch(a.batch, a.img)
+    # synthetic inputs of the shapes train_BE_font.py feeds (generated here: the oracle is only the cpu_baseline leg below)
+    gen = torch.Generator().manual_seed(8642 + rank)
+    imgs = torch.rand(a.batch, 3, a.img, a.img, generator=gen)
+    masks = (torch.rand(a.batch, 1, a.img, a.img, generator=gen) > 0.5).float()
+    edges = (torch.rand(a.batch, 1, a.img, a.img, generator=gen) > 0.8).float()
+    labels = torch.randint(0, 143, (a.batch,), generator=gen)
+    cls = torch.zeros(a.batch, 143)
+    cls[torch.arange(a.batch), labels] = 1
+    y = {"cls": cls, "cnt_style": torch.rand(a.batch, 5, generator=gen)}
     dimgs, dmasks, dedges, dlabels = imgs.to(dev), masks.to(dev), edges.to(dev), labels.to(dev)
     dy = {k: v.to(dev) for k, v in y.items()}
     ones, zeros = torch.ones((a.batch, 1), device=dev), torch.zeros((a.batch, 1), device=dev)
@@ -108,6 +114,8 @@ def main():
         torch.distributed.destroy_process_group()
         return
     if a.cpu_steps > 0:
+        from oracle import ref_cpu as O      # checker / CPU baseline only
+        from oracle import ref_font as FN
         torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
         O.require_grad(pn); O.require_grad(pd)
         o1 = torch.optim.Adam([pn[n] for n in O.trainable_names(pn)], lr=1e-4)
