@@ -432,6 +432,9 @@ class FusedVAEStep:
                 if i > 0:
                     bwd.add("vp_conv5_scatter_bf16x3", P(gS), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
                             flops=fl, tag=f"enc{i}.dgrad")                                 # cur = d a_{i-1}
+                if i == max(L - 2, 1):
+                    # the gradients of encoder.conv[i:] (16.4 of the 17 MB of conv parameters at config 3) are issued: third bucket
+                    self._bwd_b_enc_tail, self._enc_tail_first = len(bwd.calls), i
             else:
                 bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)            # other = d c_i
                 # side stream only for the last layer of the walk (i == 0): nothing rewrites `other` after it
@@ -461,7 +464,7 @@ class FusedVAEStep:
 
     # ---- execution ---------------------------------------------------------------------------
     def _launch_all(self, timers: Optional[dict] = None, on_decoder_grads=None, on_dense_grads=None, on_fc_wgrad=None,
-                    after_forward=None):
+                    after_forward=None, on_encoder_tail=None):
         s = torch.cuda.current_stream().cuda_stream
         # instrumented steps run the serial schedule: an event pair around a kernel that shares the GPU with another
         # stream's kernels would time the mixture, not the kernel
@@ -484,7 +487,13 @@ class FusedVAEStep:
             self._bwd_b.run(s, timers, 0, self._bwd_b_dense_done)
         if on_dense_grads is not None:
             on_dense_grads()
-        self._bwd_b.run(s, timers, self._bwd_b_dense_done, side=side)
+        tail = getattr(self, "_bwd_b_enc_tail", None)
+        if on_encoder_tail is not None and tail is not None:
+            self._bwd_b.run(s, timers, self._bwd_b_dense_done, tail, side=side)
+            on_encoder_tail(side)
+            self._bwd_b.run(s, timers, tail, side=side)
+        else:
+            self._bwd_b.run(s, timers, self._bwd_b_dense_done, side=side)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side[0])
         torch.add(self.recon, self.kl_sum, out=self._loss_num)
@@ -498,7 +507,7 @@ class FusedVAEStep:
         return self._side
 
     def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None,
-                         on_dense_grads=None, on_fc_wgrad=None, after_forward=None):
+                         on_dense_grads=None, on_fc_wgrad=None, after_forward=None, on_encoder_tail=None):
         """Gradients of (BCE_sum + KL_sum)/B land in the optimiser's flat gradient arena.
         Returns (loss, recon, kl) as device scalars (no host sync).  ``timers`` =
         {"names": set of entry points, "events": []} brackets those launches with HIP events
@@ -507,10 +516,10 @@ class FusedVAEStep:
             self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
         self._bind_inputs(x, eps)
         if self._graph is not None and timers is None and on_decoder_grads is None and on_dense_grads is None \
-                and on_fc_wgrad is None and after_forward is None:
+                and on_fc_wgrad is None and after_forward is None and on_encoder_tail is None:
             self._graph.replay()
         else:
-            self._launch_all(timers, on_decoder_grads, on_dense_grads, on_fc_wgrad, after_forward)
+            self._launch_all(timers, on_decoder_grads, on_dense_grads, on_fc_wgrad, after_forward, on_encoder_tail)
         # BatchNorm num_batches_tracked is advanced lazily in sync_counters()
         self._steps_since_sync = getattr(self, "_steps_since_sync", 0) + 1
         return self._loss_num / self.B, self.recon, self.kl_sum
@@ -586,6 +595,24 @@ class FusedVAEStep:
             dense = self._encoder_dense_start()
             works = []
             factored = os.environ.get("VP_DP_FACTORED", "1") != "0"
+            # fourth cut: encoder.conv[i:] for the deepest blocks -- almost all of the encoder's conv parameters -- is reduced
+            # while the remaining shallow blocks still run backward, so that only their < 1 MB is left for the exposed
+            # all-reduce at the end of the step.  Its weight gradients are produced on the side stream and its BatchNorm
+            # gradients on the main stream: the collective is issued from the side stream after it has joined the main one.
+            tail_lo = dense
+            if getattr(self, "_bwd_b_enc_tail", None) is not None and os.environ.get("VP_DP_ENC_TAIL", "1") != "0":
+                off = {id(p): o for p, o in zip(self.opt.arena.params, self.opt.arena.offsets)}
+                tail_lo = off[id(self.vae.encoder.conv[self._enc_tail_first].conv.weight)]
+
+            def enc_tail(side):
+                if tail_lo >= dense:
+                    return
+                if side is not None:
+                    side[0].wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side[0]):
+                        works.append(parallel.allreduce_flat_grads(g[tail_lo:dense], self.group, async_op=True))
+                else:
+                    works.append(parallel.allreduce_flat_grads(g[tail_lo:dense], self.group, async_op=True))
             if factored:
                 # fc.0's weight gradient (134 MB of the 213 MB at config 3) is dW = dh^T flat, a sum of B outer products
                 # per rank: exchange the two factors (W x 4.3 MB all-gather) and contract over all W*B rows locally
@@ -613,14 +640,14 @@ class FusedVAEStep:
                     works.append(parallel.allreduce_flat_grads(g[fc_hi:cut], self.group, async_op=True))
 
                 out = self.forward_backward(
-                    x, eps, timers, after_forward=after_fwd, on_fc_wgrad=fc_wgrad, on_dense_grads=dense_bucket,
+                    x, eps, timers, after_forward=after_fwd, on_fc_wgrad=fc_wgrad, on_dense_grads=dense_bucket, on_encoder_tail=enc_tail,
                     on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)))
             else:
                 out = self.forward_backward(
-                    x, eps, timers,
+                    x, eps, timers, on_encoder_tail=enc_tail,
                     on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)),
                     on_dense_grads=lambda: works.append(parallel.allreduce_flat_grads(g[dense:cut], self.group, async_op=True)))
-            works.append(parallel.allreduce_flat_grads(g[:dense], self.group, async_op=True))
+            works.append(parallel.allreduce_flat_grads(g[:tail_lo], self.group, async_op=True))
             for w in works:
                 if w is not None:
                     w.wait()
