@@ -581,10 +581,11 @@ class FusedVAEStep:
     def step(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, overlap: bool = True):
         """One full training step: fwd + loss + bwd, SUM all-reduce of the flat gradient arena, fused update.
 
-        With several ranks the arena is reduced as three buckets of the same flat buffer, each handed to RCCL as
+        With several ranks the arena is reduced as four buckets of the same flat buffer, each handed to RCCL as
         soon as its gradients are final so that the all-reduce runs on the communicator's stream underneath the rest
         of backward: the decoder slice after the decoder's backward, the encoder's dense slice (fc.0 is 134 MB of the
-        213 MB at config 3) after its weight gradient, and the encoder's conv slice (17 MB) after backward; the
+        213 MB at config 3) after its weight gradient, the deep encoder blocks' conv slice (16.4 MB) while the shallow blocks
+        still run backward, and the rest of the encoder's conv slice (< 1 MB) after backward; the
         optimiser kernel waits for all three.  ``overlap=False`` issues one all-reduce of the whole arena.
         (Updating each slice right after its all-reduce, on a second side stream underneath the rest of backward, was
         measured and is NOT done: the HBM-bound optimiser kernel slows the concurrent kernels by more than it hides,
