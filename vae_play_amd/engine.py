@@ -586,7 +586,7 @@ class FusedVAEStep:
         of backward: the decoder slice after the decoder's backward, the encoder's dense slice (fc.0 is 134 MB of the
         213 MB at config 3) after its weight gradient, the deep encoder blocks' conv slice (16.4 MB) while the shallow blocks
         still run backward, and the rest of the encoder's conv slice (< 1 MB) after backward; the
-        optimiser kernel waits for all three.  ``overlap=False`` issues one all-reduce of the whole arena.
+        optimiser kernel waits for all of them.  ``overlap=False`` issues one all-reduce of the whole arena.
         (Updating each slice right after its all-reduce, on a second side stream underneath the rest of backward, was
         measured and is NOT done: the HBM-bound optimiser kernel slows the concurrent kernels by more than it hides,
         4.52 vs 4.46 ms/step on one GPU; ``optim.*.step_range`` remains available.)"""
