@@ -130,7 +130,7 @@ def _worker_gpu(rank, port, out_dir):
     opt = optim.Adam(vae.parameters(), lr=1e-4)
     fused = engine.FusedVAEStep(vae, opt, hi - lo, S, C, precision="f32")   # the collective is what is under test
     assert abs(opt.grad_scale - 1.0 / WORLD) < 1e-12
-    # fused.step() = fwd/bwd + two-bucket all-reduce (decoder slice overlapped with the encoder backward) + Adam;
+    # fused.step() = fwd/bwd + bucketed all-reduce (four slices of the arena, each overlapped with the rest of backward; fc.0 as two factors) + Adam;
     # intercept the optimiser to read the reduced gradients before the update consumes them
     grads = {}
     real_step = opt.step
