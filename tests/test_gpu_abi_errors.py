@@ -40,6 +40,26 @@ def test_bad_arguments_and_short_workspaces_are_refused():
     assert b"workspace" in lib.vp_last_error()
     assert lib.vp_bn_stats_f32(P(x), 128, 16, 1e-5, 0.9, P(torch.empty(16, device=DEV)), P(torch.empty(16, device=DEV)), None, None,
                                P(small), 4, st) == -3
+    # k x k split-bf16 entry points: kernel sizes 1 / 3 / 5 only; padded planes need a multiple of 8 that covers C
+    assert lib.vp_conv_gather_bf16x3(P(xs), P(ws_), None, P(y), 2, 4, 4, 8, 8, 16, 8, 2, 2, 0, st) == -1
+    assert b"kernel size" in lib.vp_last_error()
+    assert lib.vp_pack_w_split(P(w), P(ws_), None, 8, 16, 7, st) == -1 and b"kernel size" in lib.vp_last_error()
+    pad = torch.empty((2, 64 * 8), dtype=torch.int16, device=DEV)
+    assert lib.vp_split_pad_f32(P(x), P(pad), 64, 3, 12, st) == -1 and b"multiple of 8" in lib.vp_last_error()
+    assert lib.vp_split_pad_f32(P(x), P(pad), 64, 9, 8, st) == -1
+    assert lib.vp_split_pad_f32(P(x), P(pad), 64, 3, 8, st) == 0
+    torch.cuda.synchronize()
+    hi = pad[0].view(64, 8)
+    assert int(hi[:, 3:].abs().max()) == 0, "padding channels must be zero"
+    # skinny dense kernels: a split workspace that is too small is refused like everywhere else
+    a_ = torch.randn(4, 4096, device=DEV); b_ = torch.randn(256, 4096, device=DEV); c_ = torch.empty(4, 256, device=DEV)
+    need_g = lib.vp_gemm_workspace_bytes(4, 256, 4096)
+    assert need_g > 0
+    assert lib.vp_gemm_f32(P(a_), 4096, 1, P(b_), 4096, 1, P(c_), 256, None, 4, 256, 4096, 0, P(small), 16, st) == -3
+    wsg = torch.empty(need_g // 4, device=DEV)
+    assert lib.vp_gemm_f32(P(a_), 4096, 1, P(b_), 4096, 1, P(c_), 256, None, 4, 256, 4096, 0, P(wsg), need_g, st) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(c_.cpu(), a_.cpu() @ b_.cpu().t(), rtol=1e-4, atol=1e-3)
     # more than 32 layouts in one pack batch
     jobs = (_lib.PackJob * 20)(*[_lib.PackJob(w.data_ptr(), w.data_ptr(), w.data_ptr(), 8, 16, 0, 0) for _ in range(20)])
     assert lib.vp_pack_w5_batch(jobs, 20, st) == -1 and b"32" in lib.vp_last_error()
