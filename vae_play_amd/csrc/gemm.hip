@@ -285,7 +285,9 @@ inline int skinny_nsplit(int mode, long M, long N, long K) {
   if (const char* e = getenv("VP_GEMM_SKINNY")) if (atoi(e) == 0) return 0;   // A/B knob
   const long colblocks = (N + 127) / 128;
   const long unit = mode == 0 ? 256 : 4 * SK_KT;      // smallest K range worth a workgroup
-  long want = (512 + colblocks - 1) / colblocks;
+  long blocks = 512;
+  if (const char* e = getenv("VP_SKINNY_BLOCKS")) blocks = atol(e);            // A/B knob
+  long want = (blocks + colblocks - 1) / colblocks;
   long maxs = K / unit;
   if (maxs < 1) maxs = 1;
   long s = want < maxs ? want : maxs;
