@@ -163,6 +163,12 @@ static bool halo_enabled() {
   return on;
 }
 
+// layers with fewer output tiles than this split K in two (A/B knob VP_CONV_SPLIT_TILES)
+static long conv_split_tiles() {
+  const char* e = getenv("VP_CONV_SPLIT_TILES");
+  return e ? atol(e) : 384;
+}
+
 template <class PF>
 static int gather16_t(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws, int Hb,
                       int Wb, int Cbig, int Csmall, int ks, int stride, int act, bool plain5, vp_stream stream) {
@@ -176,7 +182,7 @@ static int gather16_t(const void* big_split, const void* w_p0_split, const float
   // few output tiles and a long K (the 8x8-resolution layers: 256 workgroups = one per CU): split K in two and
   // accumulate both halves with fp32 atomics onto a zeroed output (two addends: the sum does not depend on order)
   const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64);
-  p.nsplit = (plain5 && !bias && act == VP_ACT_NONE && Cbig % 64 == 0 && tiles < 384 && p.K >= 4096) ? 2 : 1;
+  p.nsplit = (plain5 && !bias && act == VP_ACT_NONE && Cbig % 64 == 0 && tiles < conv_split_tiles() && p.K >= 4096) ? 2 : 1;
   p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
   if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
@@ -195,7 +201,7 @@ static int scatter16_t(const void* small_split, const void* w_p1_split, float* b
   p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * p.g.nt;
   p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
   const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64) * stride * stride;
-  p.nsplit = (plain5 && Csmall % 64 == 0 && tiles < 384 && 4 * Csmall >= 1024) ? 2 : 1;
+  p.nsplit = (plain5 && Csmall % 64 == 0 && tiles < conv_split_tiles() && 4 * Csmall >= 1024) ? 2 : 1;
   if (p.nsplit == 2 &&
       hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
