@@ -19,6 +19,8 @@
 //    step), so no transpose pass through HBM or VALU is needed;
 //  * accumulator layout and store path identical to igemm.h (lane = output channel).
 #pragma once
+#include <stdio.h>
+#include <string.h>
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "problems.h"
@@ -602,6 +604,16 @@ inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
   long MINB = 384;
   if (const char* e = getenv("VP_TILE_BLOCKS")) MINB = atol(e);          // A/B knob
+  if (const char* e = getenv("VP_TILE_OVERRIDE")) {                      // A/B knob: "MxNxgz:BMxBN,..." per launch shape
+    char key[64];
+    snprintf(key, sizeof(key), "%ldx%ldx%d:", M, N, gz);
+    if (const char* q = strstr(e, key)) {
+      int bm = 0, bn = 0;
+      if (sscanf(q + strlen(key), "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) && !(bm == 64 && bn == 128))
+        return {bm, bn};
+    }
+  }
+  if (getenv("VP_TILE_LOG")) fprintf(stderr, "tile16 %ldx%ldx%d\n", M, N, gz);
   // a 32-column operand (the 32-channel end of the last decoder block): 64-column tiles would idle half the MFMAs
   if (N <= 32 && M >= 128) return (M >= 256 && blocks(256, 32) >= MINB) ? Tile16{256, 32} : Tile16{128, 32};
   if (M >= 128 && N >= 128 && blocks(128, 128) >= MINB) return {128, 128};
