@@ -21,73 +21,88 @@ from .blocks import Conv2d, GlobalAvgPool, Linear
 from .networks_BE import EdgeNet, MaskNet
 
 
+def _halving(width: int, floor: int):
+    """Channel widths of a stack that halves ``width`` until it reaches ``floor``: (c, c/2), (c/2, c/4), ..."""
+    while width > floor:
+        yield width, width // 2
+        width //= 2
+
+
+def _doubling(width: int, cap: int, steps: int):
+    for _ in range(steps):
+        nxt = min(2 * width, cap)
+        yield width, nxt
+        width = nxt
+
+
 class ComposeNet(nn.Module):
+    """Backbone feature map -> 64 channels by (1x1, 3x3) BatchNorm pairs that halve the width -> mask and edge heads."""
+
+    _HEAD_WIDTH = 64
+
     def __init__(self, in_channels, in_size, backbone: nn.Module = None, feature_channels: int = 256):
         super().__init__()
-        target_out_channels = 64
         self.backbone = backbone
-        c = backbone.out_channels if backbone is not None else feature_channels
-        layers = []
-        for _ in range(int(math.log2(c // target_out_channels))):
-            layers.append(Conv2d(c, c // 2, 1, stride=1, bn="batch"))
-            layers.append(Conv2d(c // 2, c // 2, 3, stride=1, bn="batch"))
-            c //= 2
-        self.aux_convs = nn.Sequential(*layers)
-        self.mask_net = MaskNet(target_out_channels)
-        self.edge_net = EdgeNet(target_out_channels)
+        width = backbone.out_channels if backbone is not None else feature_channels
+        pairs = []
+        for wide, narrow in _halving(width, self._HEAD_WIDTH):
+            pairs += [Conv2d(wide, narrow, 1, stride=1, bn="batch"), Conv2d(narrow, narrow, 3, stride=1, bn="batch")]
+        self.aux_convs = nn.Sequential(*pairs)
+        self.mask_net = MaskNet(self._HEAD_WIDTH)
+        self.edge_net = EdgeNet(self._HEAD_WIDTH)
 
     def forward(self, x):
-        if self.backbone is not None:
-            x = self.backbone(x)
-            if isinstance(x, dict):
-                x = x["0"]
-        x = self.aux_convs(x)
-        return {"masks": self.mask_net(x), "edges": self.edge_net(x)}
+        feat = x if self.backbone is None else self.backbone(x)
+        if isinstance(feat, dict):               # an FPN hands back a dict of levels: the finest one is used
+            feat = feat["0"]
+        feat = self.aux_convs(feat)
+        return {"masks": self.mask_net(feat), "edges": self.edge_net(feat)}
 
 
 class MaskMapper(nn.Module):
+    """(image channel, mask) -> a pooled 1x1-projected vector and the level-weighted, flattened feature maps of every
+    (stride-2, stride-1) BatchNorm pair: the discriminator's feature-matching taps."""
+
+    _FLOOR = 16
+
     def __init__(self, in_channels, in_size, max_channel=128):
         super().__init__()
-        min_in_size = 16
-        repeat_num = int(math.log2(in_size // min_in_size)) - 2
-        self.convs = nn.Sequential(Conv2d(in_channels, 16, 3, 2, bn=None, activate="lrelu"),
-                                   Conv2d(16, 32, 3, 2, bn=None, activate="lrelu"))
-        in_channels = 32
-        out_channels = min(in_channels * 2, max_channel)
+        lrelu = dict(bn=None, activate="lrelu")
+        self.convs = nn.Sequential(Conv2d(in_channels, 16, 3, 2, **lrelu), Conv2d(16, 32, 3, 2, **lrelu))
         self.feat_modules = nn.ModuleList()
-        for _ in range(repeat_num):
-            self.feat_modules.append(nn.Sequential(Conv2d(in_channels, out_channels, 3, 2, bn="batch", activate="lrelu"),
-                                                   Conv2d(out_channels, out_channels, 3, 1, bn="batch", activate="lrelu")))
-            in_channels = out_channels
-            out_channels = min(in_channels * 2, max_channel)
-        self.pooler = nn.Sequential(Conv2d(in_channels, max_channel, 1, 1, bn=None, activate=None), GlobalAvgPool())
+        width = 32
+        for cin, cout in _doubling(32, max_channel, int(math.log2(in_size // self._FLOOR)) - 2):
+            self.feat_modules.append(nn.Sequential(Conv2d(cin, cout, 3, 2, bn="batch", activate="lrelu"),
+                                                   Conv2d(cout, cout, 3, 1, bn="batch", activate="lrelu")))
+            width = cout
+        self.pooler = nn.Sequential(Conv2d(width, max_channel, 1, 1, bn=None, activate=None), GlobalAvgPool())
 
     def forward(self, x, m):
-        x = torch.cat([x, m], dim=1)
-        x = self.convs(x)
-        feat_list = []
-        for idx, mod in enumerate(self.feat_modules):
-            x = mod(x)
-            feat_list.append(x.reshape(x.size(0), -1) * (idx // 2 + 1))
-        feat_list = torch.cat(feat_list, dim=1)
-        x = self.pooler(x)
-        return x.reshape(x.size(0), -1), feat_list
+        h = self.convs(torch.cat([x, m], dim=1))
+        taps = []
+        for level, stage in enumerate(self.feat_modules):
+            h = stage(h)
+            taps.append(h.flatten(1) * (level // 2 + 1))
+        return self.pooler(h).flatten(1), torch.cat(taps, dim=1)
 
 
 class Discriminator(nn.Module):
+    """Two MaskMappers -- (image, mask) "content" and (image, edge) "boundary" -- and a three-layer dense classifier over
+    their pooled vectors; the concatenated taps are returned for the feature-matching loss."""
+
+    _WIDTH = 64
+
     def __init__(self, in_channels, in_size, num_classes):
         super().__init__()
-        max_channel = 64
+        w = self._WIDTH
         self.num_classes = num_classes
-        self.content_disc = MaskMapper(2, in_size, max_channel=max_channel)
-        self.boundary_disc = MaskMapper(2, in_size, max_channel=max_channel)
-        self.predictor = nn.Sequential(Linear(max_channel * 2, max_channel * 2, bias=True, activate="lrelu"),
-                                       Linear(max_channel * 2, max_channel, bias=True, activate="lrelu"),
-                                       Linear(max_channel, num_classes, bias=False, activate=None))
+        self.content_disc = MaskMapper(2, in_size, max_channel=w)
+        self.boundary_disc = MaskMapper(2, in_size, max_channel=w)
+        self.predictor = nn.Sequential(Linear(2 * w, 2 * w, bias=True, activate="lrelu"), Linear(2 * w, w, bias=True, activate="lrelu"),
+                                       Linear(w, num_classes, bias=False, activate=None))
 
     def forward(self, x, m1, m2):
-        x = x[:, 0, :, :].reshape(x.size(0), 1, x.size(2), x.size(3))
-        x_m1, feats_m1 = self.content_disc(x, m1)
-        x_m2, feats_m2 = self.boundary_disc(x, m2)
-        feats = torch.cat([feats_m1, feats_m2], dim=1)
-        return self.predictor(torch.cat([x_m1, x_m2], dim=1)), feats
+        gray = x[:, :1]                           # the first image channel, kept as a 1-channel map
+        vec1, taps1 = self.content_disc(gray, m1)
+        vec2, taps2 = self.boundary_disc(gray, m2)
+        return self.predictor(torch.cat([vec1, vec2], dim=1)), torch.cat([taps1, taps2], dim=1)
