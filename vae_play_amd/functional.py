@@ -13,6 +13,8 @@ Reference ops replaced (relative to the reference checkout):
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -101,6 +103,15 @@ class _Conv5(Function):
                     dyp = torch.zeros((B, H, W, 8), dtype=torch.float32, device=dy.device)
                     dyp[..., :Cs] = dy.permute(0, 2, 3, 1)
                     dx = ops.conv5_scatter_bf16x3(ops.split_f32(dyp), (B, 8, H, W), ops.pack_w5_p1_split_padded(weight, 8), Cb, 1)
+                elif _PRECISION == "bf16x3" and Cb < 8 and Cs % 8 == 0 and os.environ.get("VP_NARROW_DGRAD16", "1") != "0":
+                    # the image side of a FIRST conv whose input gradient is needed (the VAE-GAN discriminator's, models/
+                    # networks.py:160-163: its input is the decoder's output): zero-pad the weight's input channels to 8,
+                    # scatter on the split-bf16 kernels, keep the real channels.  The exact-f32 scatter to one output channel
+                    # pads the MFMA tile's 32 columns by 97 %: 522 us against 32 + 214 us at 48 images of 128 x 128
+                    # (tools/microbench_narrow_dgrad.py)
+                    wpad = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 8 - Cb))
+                    _, p1 = ops.pack_w5_split(wpad, False, True)
+                    dx = ops.conv5_scatter_bf16x3(ops.split_f32(dy), dy.shape, p1, 8, ctx.stride)[:, :Cb]
                 else:
                     _, p1 = ops.pack_w5(weight, False, True)
                     dx = ops.conv5_scatter(dy, p1, ctx.stride)
