@@ -105,3 +105,18 @@ def test_optimizer_state_round_trip_on_device(tmp_path):
         o.step()
     for p, q in zip(net.parameters(), net2.parameters()):
         assert torch.equal(p, q)
+
+
+def test_every_script_compiles():
+    """tools/, tests/diag/, examples/, profiles/*.py and the two root entry points are scripts that only run on a GPU box:
+    keep at least their syntax under the CPU suite."""
+    import glob
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    for sub in ("tools", os.path.join("tests", "diag"), "examples", "profiles"):
+        files += sorted(glob.glob(os.path.join(root, sub, "*.py")))
+    assert len(files) > 20
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
