@@ -104,6 +104,21 @@ int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const 
                            int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream);
 int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, float* big_out,
                             int B, int Hs, int Ws, int Csmall, int Cbig, int stride, vp_stream stream);
+/* Convolution + BatchNorm batch statistics in one call (replaces nn.Conv2d / nn.ConvTranspose2d followed by the statistics
+ * pass of nn.BatchNorm2d(momentum=0.9), models/networks.py:14-16,27-28 and :38-40,43-44): the convolution's epilogue emits
+ * per-workgroup {pivot, sum(x - pivot), sum((x - pivot)^2)} per output channel from its accumulators and one finaliser
+ * launch produces mean / rstd and updates the running buffers exactly as vp_bn_stats_f32 does -- the activation is not read
+ * again for its statistics.  family: 0 = gather, 1 = scatter.  vp_conv5_stats_workspace_bytes() == 0 means that this launch
+ * shape cannot emit statistics (split-K layers, the narrow-channel halo kernels): use the plain entry point + vp_bn_stats_f32. */
+size_t vp_conv5_stats_workspace_bytes(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int stride);
+int vp_conv5_gather_stats_bf16x3(const void* big_split, const void* w_p0_split, float* small_out,
+                                 int B, int Hs, int Ws, int Cbig, int Csmall, int stride, float eps, float momentum,
+                                 float* mean, float* rstd, float* running_mean, float* running_var,
+                                 void* ws, size_t ws_bytes, vp_stream stream);
+int vp_conv5_scatter_stats_bf16x3(const void* small_split, const void* w_p1_split, float* big_out,
+                                  int B, int Hs, int Ws, int Csmall, int Cbig, int stride, float eps, float momentum,
+                                  float* mean, float* rstd, float* running_mean, float* running_var,
+                                  void* ws, size_t ws_bytes, vp_stream stream);
 size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride);
 int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref,
                           int B, int Hs, int Ws, int Cbig, int Csmall, int stride,

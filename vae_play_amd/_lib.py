@@ -48,6 +48,9 @@ SIGNATURES = {
     "vp_conv_wgrad_bf16x3": (c_int, [P, P, P] + [c_int] * 9 + [P, c_size_t, P]),
     "vp_conv5_gather_bf16x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_scatter_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_conv5_stats_workspace_bytes": (c_size_t, [c_int] * 7),
+    "vp_conv5_gather_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_conv5_scatter_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_conv5_wgrad_bf16x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vp_conv5_wgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "vp_bn_act_fwd_split_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),

@@ -169,9 +169,21 @@ static long conv_split_tiles() {
   return e ? atol(e) : 384;
 }
 
+// split-K decisions (shared by the launchers and by the statistics plan)
+static int gather_nsplit(long M, int N, int K, int Cbig, bool plain5, bool has_bias, int act) {
+  // few output tiles and a long K (the 8x8-resolution layers: 256 workgroups = one per CU): split K in two and
+  // accumulate both halves with fp32 atomics onto a zeroed output (two addends: the sum does not depend on order)
+  const long tiles = ((M + 127) / 128) * ((N + 63) / 64);
+  return (plain5 && !has_bias && act == VP_ACT_NONE && Cbig % 64 == 0 && tiles < conv_split_tiles() && K >= 4096) ? 2 : 1;
+}
+static int scatter_nsplit(long M, int N, int Csmall, int stride, bool plain5) {
+  const long tiles = ((M + 127) / 128) * ((N + 63) / 64) * stride * stride;
+  return (plain5 && Csmall % 64 == 0 && tiles < conv_split_tiles() && 4 * Csmall >= 1024) ? 2 : 1;
+}
+
 template <class PF>
 static int gather16_t(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws, int Hb,
-                      int Wb, int Cbig, int Csmall, int ks, int stride, int act, bool plain5, vp_stream stream) {
+                      int Wb, int Cbig, int Csmall, int ks, int stride, int act, bool plain5, vp_stream stream, float* stat = nullptr) {
   PF p;
   p.zero = vp_zero_page();
   p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
@@ -179,10 +191,9 @@ static int gather16_t(const void* big_split, const void* w_p0_split, const float
   p.w = (const u16*)w_p0_split; p.w_plane = (size_t)Csmall * Cbig * p.g.nt;
   p.bias = bias; p.out = small_out; p.act = act;
   p.M = B * Hs * Ws; p.N = Csmall; p.K = p.g.nt * Cbig;
-  // few output tiles and a long K (the 8x8-resolution layers: 256 workgroups = one per CU): split K in two and
-  // accumulate both halves with fp32 atomics onto a zeroed output (two addends: the sum does not depend on order)
-  const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64);
-  p.nsplit = (plain5 && !bias && act == VP_ACT_NONE && Cbig % 64 == 0 && tiles < conv_split_tiles() && p.K >= 4096) ? 2 : 1;
+  p.nsplit = gather_nsplit(p.M, p.N, p.K, Cbig, plain5, bias != nullptr, act);
+  p.stat = stat;
+  if (stat && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_gather_stats_bf16x3: this shape splits K (use vp_bn_stats_f32)");
   p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
   if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
@@ -193,15 +204,16 @@ static int gather16_t(const void* big_split, const void* w_p0_split, const float
 
 template <class PT>
 static int scatter16_t(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb, int Csmall,
-                       int Cbig, int ks, int stride, bool plain5, vp_stream stream) {
+                       int Cbig, int ks, int stride, bool plain5, vp_stream stream, float* stat = nullptr) {
   PT p;
   p.zero = vp_zero_page();
   p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
   p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
   p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * p.g.nt;
   p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
-  const long tiles = ((long)(p.M + 127) / 128) * ((p.N + 63) / 64) * stride * stride;
-  p.nsplit = (plain5 && Csmall % 64 == 0 && tiles < conv_split_tiles() && 4 * Csmall >= 1024) ? 2 : 1;
+  p.nsplit = scatter_nsplit(p.M, p.N, Csmall, stride, plain5);
+  p.stat = stat;
+  if (stat && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_scatter_stats_bf16x3: this shape splits K (use vp_bn_stats_f32)");
   if (p.nsplit == 2 &&
       hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
@@ -375,6 +387,123 @@ static int wgrad16(const void* big_split, const void* small_split, float* dw_ref
   const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
   if (!plain5) return wgrad16_t<ProbW16K>(big_split, small_split, dw_ref, g, ns, ws, stream);
   return wgrad16_t<ProbW16>(big_split, small_split, dw_ref, g, ns, ws, stream);
+}
+
+}
+
+// ---- BatchNorm statistics from the convolution epilogue -----------------------------------------------------------------
+// A 5x5 VAE layer on the split-bf16 kernels can emit {pivot, sum(x - pivot), sum((x - pivot)^2)} per (workgroup, output channel)
+// from its accumulators (igemm16.h epilogue_stats32); one finaliser launch then produces mean / rstd / running statistics.
+// This replaces bn_partial_kernel<0>, i.e. one full read of the activation per BatchNorm layer.
+namespace {
+struct StatPlan { int ok, bm, tiles_m, gz, N; long M, R; };
+
+StatPlan stat_plan(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
+  StatPlan sp = {0, 0, 0, 0, 0, 0, 0};
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || Cbig <= 0 || Csmall <= 0 || (stride != 1 && stride != 2)) return sp;
+  if (Cbig % 8 != 0 || Csmall % 8 != 0) return sp;
+  sp.M = (long)B * Hs * Ws;
+  if (family == 0) {
+    if (halo_enabled() && halo_gather_kind(B, Hs, Ws, Cbig, Csmall, stride)) return sp;
+    sp.N = Csmall;
+    if (gather_nsplit(sp.M, sp.N, 25 * Cbig, Cbig, true, false, VP_ACT_NONE) != 1) return sp;
+    sp.gz = 1;
+    sp.R = sp.M;
+  } else {
+    if (halo_enabled() && halo_scatter_kind(B, Hs, Ws, Csmall, Cbig, stride)) return sp;
+    sp.N = Cbig;
+    if (scatter_nsplit(sp.M, sp.N, Csmall, stride, true) != 1) return sp;
+    sp.gz = stride * stride;
+    sp.R = sp.M * stride * stride;
+  }
+  const Tile16 t = choose_tile16(sp.M, sp.N, sp.gz);
+  sp.bm = t.bm;
+  sp.tiles_m = (int)((sp.M + t.bm - 1) / t.bm);
+  sp.ok = 1;
+  return sp;
+}
+}  // namespace
+
+namespace vp {
+// one 256-thread workgroup per channel; groups are shifted to the pivot of group 0 and summed in fp64:
+//   sum(x - P) = s_g + n_g d,  sum((x - P)^2) = q_g + 2 d s_g + n_g d^2,  d = p_g - P
+__global__ void __launch_bounds__(256) bn_stats_slab_final_kernel(const float* __restrict__ slab, int G, int tiles_m, int BM, long M, long R,
+                                                                  int C, float eps, float momentum, float* __restrict__ mean,
+                                                                  float* __restrict__ rstd, float* __restrict__ rm, float* __restrict__ rv) {
+  __shared__ double shs[4], shq[4];
+  const int c = blockIdx.x;
+  const float* pv = slab + ((size_t)0 * C + c) * G;
+  const float* sv = slab + ((size_t)1 * C + c) * G;
+  const float* qv = slab + ((size_t)2 * C + c) * G;
+  const double P = (double)pv[0];
+  double S = 0.0, Q = 0.0;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    const int tile = g % tiles_m;
+    const long left = M - (long)tile * BM;
+    const double n = (double)(left < BM ? left : BM);
+    const double d = (double)pv[g] - P, s = (double)sv[g], q = (double)qv[g];
+    S += s + n * d;
+    Q += q + 2.0 * d * s + n * d * d;
+  }
+  S = wave_sum_d(S);
+  Q = wave_sum_d(Q);
+  if ((threadIdx.x & 63) == 0) { shs[threadIdx.x >> 6] = S; shq[threadIdx.x >> 6] = Q; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  S = (shs[0] + shs[1]) + (shs[2] + shs[3]);
+  Q = (shq[0] + shq[1]) + (shq[2] + shq[3]);
+  const double ms = S / (double)R;
+  double var = Q / (double)R - ms * ms;
+  if (var < 0.0) var = 0.0;
+  const double m = P + ms;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
+  if (rv) {
+    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+  }
+}
+}  // namespace vp
+
+extern "C" {
+
+size_t vp_conv5_stats_workspace_bytes(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
+  const StatPlan sp = stat_plan(family, B, Hs, Ws, Cbig, Csmall, stride);
+  return sp.ok ? (size_t)3 * sp.N * sp.tiles_m * sp.gz * sizeof(float) : 0;
+}
+
+static int stats_finish(const StatPlan& sp, const float* slab, float eps, float momentum, float* mean, float* rstd, float* rm, float* rv,
+                        vp_stream stream) {
+  hipLaunchKernelGGL(bn_stats_slab_final_kernel, dim3(sp.N), dim3(256), 0, (hipStream_t)stream, slab, sp.tiles_m * sp.gz, sp.tiles_m, sp.bm,
+                     sp.M, sp.R, sp.N, eps, momentum, mean, rstd, rm, rv);
+  return check_launch("vp_conv5_*_stats_bf16x3(final)");
+}
+
+int vp_conv5_gather_stats_bf16x3(const void* big_split, const void* w_p0_split, float* small_out, int B, int Hs, int Ws, int Cbig,
+                                 int Csmall, int stride, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                                 float* running_var, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(big_split && w_p0_split && small_out && mean && rstd && ws, "vp_conv5_gather_stats_bf16x3: null pointer");
+  const StatPlan sp = stat_plan(0, B, Hs, Ws, Cbig, Csmall, stride);
+  VP_REQUIRE(sp.ok, "vp_conv5_gather_stats_bf16x3: this shape cannot emit statistics (vp_conv5_stats_workspace_bytes() == 0)");
+  if (ws_bytes < (size_t)3 * sp.N * sp.tiles_m * sp.gz * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_gather_stats_bf16x3: workspace too small");
+  int rc = gather16_t<ProbF16>(big_split, w_p0_split, nullptr, small_out, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride,
+                               VP_ACT_NONE, true, stream, (float*)ws);
+  if (rc) return rc;
+  return stats_finish(sp, (const float*)ws, eps, momentum, mean, rstd, running_mean, running_var, stream);
+}
+
+int vp_conv5_scatter_stats_bf16x3(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Csmall,
+                                  int Cbig, int stride, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                                  float* running_var, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(small_split && w_p1_split && big_out && mean && rstd && ws, "vp_conv5_scatter_stats_bf16x3: null pointer");
+  const StatPlan sp = stat_plan(1, B, Hs, Ws, Cbig, Csmall, stride);
+  VP_REQUIRE(sp.ok, "vp_conv5_scatter_stats_bf16x3: this shape cannot emit statistics (vp_conv5_stats_workspace_bytes() == 0)");
+  if (ws_bytes < (size_t)3 * sp.N * sp.tiles_m * sp.gz * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_scatter_stats_bf16x3: workspace too small");
+  int rc = scatter16_t<ProbT16>(small_split, w_p1_split, big_out, B, Hs, Ws, Hs * stride, Ws * stride, Csmall, Cbig, 5, stride, true, stream,
+                                (float*)ws);
+  if (rc) return rc;
+  return stats_finish(sp, (const float*)ws, eps, momentum, mean, rstd, running_mean, running_var, stream);
 }
 
 }

@@ -77,6 +77,10 @@ struct ProbF16T {
   ConvGeom g; int act; int M, N, K;
   int nsplit, k_per_split;   // nsplit == 2: both halves of K are atomically added onto a zeroed output
   int xcd_map;               // remap (blockIdx.x, blockIdx.y) so that column tiles of one row tile share an XCD
+  // BatchNorm statistics from the epilogue (nsplit == 1 only): per workgroup and output channel {pivot, sum(x - pivot),
+  // sum((x - pivot)^2)} over the workgroup's valid rows, slab layout [3][N][groups], group = blockIdx.z * row tiles + row tile
+  static constexpr bool HAS_STAT = true;
+  float* stat = nullptr;
   struct ZCtx { int k_begin, k_end; };
   struct ARow { int pix_base, h0, w0, valid; };
   struct BRow { int off, valid; };
@@ -171,6 +175,8 @@ struct ProbT16T {
   float* out; const void* zero; ConvGeom g; int M, N;
   int nsplit;                // 1, or 2: z = phase*2 + half, halves atomically added onto a zeroed output
   int xcd_map;
+  static constexpr bool HAS_STAT = true;
+  float* stat = nullptr;     // see ProbF16T
   struct ZCtx { int k_begin, k_end, ph, pw, th, tw, r0h, r0w, bh, bw; };   // phase geometry as in problems.h ProbT
   struct ARow { int pix_base, q, p, valid; };
   struct BRow { int off, valid; };
@@ -267,6 +273,7 @@ struct ProbW16T {
   VP_HD int pad() const { return K5 ? 2 : g.pad; }
   VP_HD int nt() const { return K5 ? 25 : g.nt; }
   static constexpr bool A_KM = true, B_KM = true;
+  static constexpr bool HAS_STAT = false;
   const u16* big; size_t big_plane;
   const u16* small; size_t small_plane;
   float* slab; const void* zero; ConvGeom g; int M, N, K; int nsplit, k_per_split;
@@ -339,6 +346,51 @@ __device__ __forceinline__ bf16x8_t frag16(const unsigned char* plane, int row, 
     const bf16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(p0));
     const bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(p0 + 4 * S));
     return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+// BatchNorm statistics of the workgroup's output tile, taken from the accumulators (32x32 MFMA layout: lane = column,
+// rows in the 16 registers): replaces one full read of the activation by bn_partial_kernel<0>.  Sums are pivoted on the
+// tile's first row (see bn.hip: raw sum(x^2) loses log2(mean^2/var) bits), combined across the wave rows through LDS in a
+// fixed order and written as {pivot, sum(x - pivot), sum((x - pivot)^2)} per (channel, group).  Call with every wave past its
+// last LDS read of the main loop (a barrier).  `group` = blockIdx.z * (row tiles) + row tile, `groups` = their total.
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void epilogue_stats32(float* __restrict__ stat, int groups, int group, int M, int N, const f32x16_t (&acc)[TM][TN],
+                                                 unsigned char* lds, int m0, int n0, int wm, int wn, int li, int lh, int tid) {
+  float* pv = reinterpret_cast<float*>(lds);      // [BN] pivots
+  float* red = pv + BN;                            // [WM][BN][2]
+  if (wm == 0 && lh == 0) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) pv[wn * (BN / WN) + 32 * j + li] = acc[0][j][0];   // row m0 (always < M)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * (BN / WN) + 32 * j + li;
+    const float pvt = pv[col];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float d = m < M ? acc[i][j][r] - pvt : 0.f;
+        s += d;
+        q += d * d;
+      }
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (lh == 0) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < N) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+    const size_t n = (size_t)(n0 + tid);
+    stat[(0 * (size_t)N + n) * groups + group] = pv[tid];
+    stat[(1 * (size_t)N + n) * groups + group] = s;
+    stat[(2 * (size_t)N + n) * groups + group] = q;
   }
 }
 
@@ -585,6 +637,11 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
     }
   }
 
+  if constexpr (P::HAS_STAT) {
+    if (p.stat)      // (workgroup-uniform) every wave is past its last LDS read: the loop ends with a barrier
+      epilogue_stats32<BM, BN, WM, WN, TM, TN>(p.stat, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, p.M, p.N, acc, lds, m0, n0,
+                                               wm, wn, li, lh, tid);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -10,6 +10,8 @@
 //     models/networks.py:14 with channel_in = 1 or 3): dy on the lane, x through uniform loads.
 // Partial sums go to per-workgroup slabs (no atomics -> bit-reproducible) and are combined by
 // slab_reduce_kernel into the reference weight layout.
+#include <stdlib.h>
+#include <stdint.h>
 #include "common.h"
 #include "problems.h"
 #include "narrow.h"
@@ -330,6 +332,132 @@ __global__ void __launch_bounds__(256) slab_reduce_deep_kernel(const float* __re
   }
 }
 
+
+// ---- final conv forward on the matrix cores: taps folded into the MFMA column dimension ("tap-in-N") ------------------
+// out[b,h,w,n] = act(bias[n] + sum_{tap,c} in[b, h+r-2, w+q-2, c] * w[n][tap][c]) with n <= 3 outputs is hostile to an
+// implicit GEMM (N = 3 padded to 32 columns = 10x wasted MFMA work; measured 25 % slower than the VALU kernel above).
+// Here the 25 taps x NOUT outputs ARE the column dimension: for every pixel p of the output tile's halo patch
+//     P[p][n*25 + tap] = sum_c in[p][c] * w[n][tap][c]          (one GEMM: M = pixels, N = 25*NOUT <= 96, K = C = 64)
+// and then out[h][w][n] = bias[n] + sum_tap P[(h+r-2, w+q-2)][n*25 + tap], a shifted sum of 25 LDS words per output.
+// The packed weights P0 [NOUT][25][C] viewed as [25*NOUT][C] are exactly the B operand, so nothing is re-packed.
+//   * 16x16 output pixels per workgroup, 20x20 patch = 13 MFMA row tiles of 32 pixels, dealt round-robin to the 4 waves;
+//   * A fragments straight from global memory (fp32, no LDS): MFMA k is permuted so that lane half lh owns channels
+//     32*lh .. 32*lh+31 -- a lane loads 128 contiguous bytes and the two halves of a pixel one 256-B line; the fp32
+//     values are split into bf16 hi/lo in registers (3 MFMAs per product as everywhere else); next tile prefetched;
+//   * B fragments (<= 96 rows x 64 channels) live in registers for the whole workgroup;
+//   * P goes to LDS with a 97-word row pitch (odd: the column writes and the shifted-sum reads are conflict-free).
+// 75/96 of the MFMA columns and 256/400 of the rows are useful work (50 %), still ~4x the VALU kernel's rate.
+typedef float f32x16_e __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_e __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const vp_f32x4& a, const vp_f32x4& b, bf16x8_e& h, bf16x8_e& l) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = j < 4 ? a[j] : b[j - 4];
+    const __bf16 hh = (__bf16)x;
+    h[j] = hh;
+    l[j] = (__bf16)(x - (float)hh);
+  }
+}
+
+template <int NOUT>
+__global__ void __launch_bounds__(256, 1) conv5s1_tapn_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int H, int W, int act) {
+  constexpr int C = 64, T = 16, HALO = T + 4, NPIX = HALO * HALO;     // 400 patch pixels
+  constexpr int NCOL = 25 * NOUT, NT = (NCOL + 31) / 32;               // 75 -> 3 column tiles, 25 -> 1
+  constexpr int PITCH = 32 * NT + 1;                                   // odd word pitch
+  constexpr int MT = (NPIX + 31) / 32;                                 // 13 row tiles
+  __shared__ float P[NPIX * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h0 = blockIdx.y * T, w0 = blockIdx.x * T;
+
+  // B fragments: row (32 jt + li) of the [NCOL][C] weight view, channels 32*lh + 8*s .. +7 for MFMA k-step s
+  bf16x8_e bh[NT][4], bl[NT][4];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int row = 32 * jt + li;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      vp_f32x4 a = zero4(), c = zero4();
+      if (row < NCOL) {
+        const float* q = w + (size_t)row * C + 32 * lh + 8 * s;
+        a = ld4(q);
+        c = ld4(q + 4);
+      }
+      split8(a, c, bh[jt][s], bl[jt][s]);
+    }
+  }
+
+  auto load_tile = [&](int t, vp_f32x4 (&raw)[8]) {
+    const int pi = 32 * t + li;
+    const int py = pi / HALO, px = pi - py * HALO;
+    const int gh = h0 + py - 2, gw = w0 + px - 2;
+    const bool ok = pi < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    const float* q = in + ((size_t)(b * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * C + 32 * lh;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) raw[v] = ok ? ld4(q + 4 * v) : zero4();
+  };
+
+  vp_f32x4 cur[8], nxt[8];
+  if (wave < MT) load_tile(wave, cur);
+  for (int t = wave; t < MT; t += 4) {
+    const bool more = t + 4 < MT;
+    if (more) load_tile(t + 4, nxt);
+    f32x16_e acc[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8_e ah, al;
+      split8(cur[2 * s], cur[2 * s + 1], ah, al);
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[jt][s], acc[jt], 0, 0, 0);
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[jt][s], acc[jt], 0, 0, 0);
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[jt][s], acc[jt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < NPIX) P[row * PITCH + 32 * jt + li] = acc[jt][r];
+      }
+    if (more) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) cur[v] = nxt[v];
+    }
+  }
+  __syncthreads();
+  const int tx = tid % T, ty = tid / T;
+  const int h = h0 + ty, ww = w0 + tx;
+  float sum[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) sum[n] = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const float* pp = &P[((ty + r) * HALO + tx + q) * PITCH + r * 5 + q];
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) sum[n] += pp[n * 25];
+    }
+  if (h < H && ww < W) {
+    float* o = out + ((size_t)(b * H + h) * W + ww) * NOUT;
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+      float v = sum[n];
+      if (act == ACT_SIGMOID) v = 1.f / (1.f + __builtin_expf(-v));
+      o[n] = v;
+    }
+  }
+}
+
 // ---- host dispatch ------------------------------------------------------------------------------
 bool narrow_gather_applicable(const ConvGeom& g, int act) {
   return g.ks == 5 && g.Hb == g.Hs && g.Wb == g.Ws && g.stride == 1 && (g.Cs == 1 || g.Cs == 3) && g.Cb % 16 == 0 && (act == ACT_NONE || act == ACT_SIGMOID);
@@ -338,6 +466,13 @@ bool narrow_gather_applicable(const ConvGeom& g, int act) {
 int narrow_gather_launch(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g, int act,
                          hipStream_t s) {
   dim3 grid((g.Ws + 15) / 16, (g.Hs + 15) / 16, g.B);
+  // 64 input channels (every decoder of models/networks.py ends in 64): the matrix-core kernel; VP_TAPN=0 keeps the VALU kernel
+  static const bool tapn = [] { const char* e = getenv("VP_TAPN"); return !e || atoi(e) != 0; }();
+  if (tapn && g.Cb == 64 && ((uintptr_t)big & 15) == 0 && ((uintptr_t)w_p0 & 15) == 0) {
+    if (g.Cs == 3) hipLaunchKernelGGL((conv5s1_tapn_kernel<3>), grid, dim3(256), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, act);
+    else hipLaunchKernelGGL((conv5s1_tapn_kernel<1>), grid, dim3(256), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, act);
+    return check_launch("conv5s1_tapn");
+  }
   if (g.Cs == 3)
     hipLaunchKernelGGL((conv5s1_smallout_kernel<3>), grid, dim3(256), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, g.Cb, act);
   else

@@ -142,7 +142,6 @@ class FusedVAEStep:
         lib = _lib.load()
         B, S, C, Z, L = self.B, self.S, self.C, self.Z, self.L
         enc, dec = self.vae.encoder, self.vae.decoder
-        mom, eps_bn = 0.9, 1e-5
         fwd, bwd = _Plan(), _Plan()
         P = _ptr
         pack_jobs = []   # every conv weight is re-packed by ONE launch at the head of the forward plan
@@ -150,6 +149,7 @@ class FusedVAEStep:
         # the next layer's HBM-bound BatchNorm backward.  The split output gradient they read is ping-ponged between
         # two buffers; before a buffer is rewritten the main stream waits for the weight gradient that read it.
         side_on = self.precision == "bf16x3"
+        x3 = self.precision == "bf16x3"
         n_side = [0]
 
         def side_slot():
@@ -172,17 +172,36 @@ class FusedVAEStep:
                 raise _lib.VaePlayHipError("parameter has no arena gradient; build the optimiser first")
             return p.grad
 
-        x3 = self.precision == "bf16x3"
-
         def use16(cin, cout):
             return x3 and cin % 8 == 0 and cout % 8 == 0
 
-        def bn_block(tag, x_buf, R, Cn, bn_mod, y_buf, y_split=None):
-            """stats + fused normalise/ReLU (fp32 and/or split output); returns the saved (mean, rstd)."""
+        fuse_stats = x3 and os.environ.get("VP_FUSE_BN_STATS", "1") != "0"
+
+        def bn_block(tag, x_buf, R, Cn, bn_mod, y_buf, y_split=None, conv=None):
+            """stats + fused normalise/ReLU (fp32 and/or split output); returns the saved (mean, rstd).
+            Momentum and eps are the module's (models/networks.py:16,40,66,89 use momentum=0.9, eps=1e-5).
+            ``conv`` = (family, entry point, leading arguments, geometry, flops, tag) of the split-bf16 convolution that produces
+            ``x_buf``: when that launch shape can emit the statistics from its epilogue the convolution and the statistics
+            become ONE call (vp_conv5_*_stats_bf16x3) and the activation is not read again for them."""
             mean, rstd = self._buf(f"{tag}.mean", Cn), self._buf(f"{tag}.rstd", Cn)
             ws = self._ws(f"{tag}.bnws", lib.vp_bn_workspace_bytes(R, Cn))
-            fwd.add("vp_bn_stats_f32", P(x_buf), R, Cn, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
-                    P(bn_mod.running_var), P(ws), ws.numel() * 4)
+            mom, eps_bn = float(bn_mod.momentum), float(bn_mod.eps)
+            fused = False
+            if conv is not None:
+                family, name, lead, geom, fl, ctag = conv
+                qgeom = geom if family == 0 else (geom[0], geom[1], geom[2], geom[4], geom[3], geom[5])   # query takes (Cbig, Csmall)
+                nst = lib.vp_conv5_stats_workspace_bytes(family, *qgeom) if fuse_stats else 0
+                if nst:
+                    st = self._ws(f"{tag}.statws", nst)
+                    fwd.add(name.replace("_bf16x3", "_stats_bf16x3"), *lead, *geom, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
+                            P(bn_mod.running_var), P(st), st.numel() * 4, flops=fl, tag=ctag)
+                    fused = True
+                else:
+                    extra = (None,) if family == 0 else ()
+                    fwd.add(name, lead[0], lead[1], *extra, lead[2], *geom, *((_ACT_NONE,) if family == 0 else ()), flops=fl, tag=ctag)
+            if not fused:
+                fwd.add("vp_bn_stats_f32", P(x_buf), R, Cn, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
+                        P(bn_mod.running_var), P(ws), ws.numel() * 4)
             fwd.add("vp_bn_act_fwd_split_f32", P(x_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(y_buf),
                     P(y_split), R, Cn, _ACT_RELU, 0.0)
             return mean, rstd, ws
@@ -214,12 +233,12 @@ class FusedVAEStep:
             n_out = B * Hs * Hs * Cout
             c = self._buf(f"enc{i}.c", n_out)
             fl = 50.0 * B * Hs * Hs * Cin * Cout
+            conv = None
             if enc16[i]:
                 p0 = self._sbuf(f"enc{i}.p0s", Cout * 25 * Cin)
                 p1 = self._sbuf(f"enc{i}.p1s", Cin * 25 * Cout)
                 pack(blk.conv.weight, p0, p1, Cout, Cin, True, first=(i == 0))
-                fwd.add("vp_conv5_gather_bf16x3", P(enc_in_s[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
-                        flops=fl, tag=f"enc{i}.fwd")
+                conv = (0, "vp_conv5_gather_bf16x3", (P(enc_in_s[-1]), P(p0), P(c)), (B, Hs, Hs, Cin, Cout, 2), fl, f"enc{i}.fwd")
             else:
                 p0 = self._buf(f"enc{i}.p0", Cout * 25 * Cin)
                 p1 = self._buf(f"enc{i}.p1", Cin * 25 * Cout) if i > 0 else None
@@ -230,7 +249,7 @@ class FusedVAEStep:
             nxt16 = i + 1 < L and enc16[i + 1]
             a = None if nxt16 else self._buf(f"enc{i}.a", n_out)
             a_s = self._sbuf(f"enc{i}.as", n_out) if nxt16 else None
-            mean, rstd, ws = bn_block(f"enc{i}", c, B * Hs * Hs, Cout, blk.bn, a, a_s)
+            mean, rstd, ws = bn_block(f"enc{i}", c, B * Hs * Hs, Cout, blk.bn, a, a_s, conv=conv)
             enc_rec.append((blk, Cin, Cout, Hs, p1, c, mean, rstd, ws))
             enc_in.append(a)
             enc_in_s.append(a_s)
@@ -276,12 +295,12 @@ class FusedVAEStep:
             n_out = B * 4 * Hs * Hs * Cout
             tbuf = self._buf(f"dec{i}.t", n_out)
             fl = 50.0 * B * Hs * Hs * Cin * Cout
+            conv = None
             if dec16[i]:
                 p1 = self._sbuf(f"dec{i}.p1s", Cout * 25 * Cin)   # T family: [Cbig=Cout][25][Csmall=Cin]
                 p0 = self._sbuf(f"dec{i}.p0s", Cin * 25 * Cout)   # F family (dgrad): [Csmall=Cin][25][Cbig=Cout]
                 pack(blk.conv.weight, p0, p1, Cin, Cout, True)
-                fwd.add("vp_conv5_scatter_bf16x3", P(dec_in_s[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
-                        flops=fl, tag=f"dec{i}.fwd")
+                conv = (1, "vp_conv5_scatter_bf16x3", (P(dec_in_s[-1]), P(p1), P(tbuf)), (B, Hs, Hs, Cin, Cout, 2), fl, f"dec{i}.fwd")
             else:
                 p1 = self._buf(f"dec{i}.p1", Cout * 25 * Cin)
                 p0 = self._buf(f"dec{i}.p0", Cin * 25 * Cout)
@@ -294,7 +313,7 @@ class FusedVAEStep:
             fin_halo = False
             u = None if nxt16 else self._buf(f"dec{i}.u", n_out)
             u_s = self._sbuf(f"dec{i}.us", n_out) if (nxt16 or fin_halo) else None
-            mean, rstd, ws = bn_block(f"dec{i}", tbuf, B * 4 * Hs * Hs, Cout, blk.bn, u, u_s)
+            mean, rstd, ws = bn_block(f"dec{i}", tbuf, B * 4 * Hs * Hs, Cout, blk.bn, u, u_s, conv=conv)
             dec_rec.append((blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws))
             dec_in.append(u)
             dec_in_s.append(u_s)
