@@ -8,11 +8,15 @@ all-reduce + Adam) on N MI355X GPUs, one process per GPU.
 
 Workload (BASELINE.json config 3): 128x128x3 images, latent 128, 32 images per GPU
 (global batch 256 at 8 GPUs -> weak scaling), synthetic uniform[0,1) pixels, random-init weights
-(VaeGan.init_parameters rule, seed 0), fp32 arithmetic on the f32 MFMA path, Adam(lr=1e-4).
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel family of the step (the
-5x5 implicit-GEMM convolutions, MFMA-bound): algorithmic FLOPs of its launches / their summed
-HIP-event durations inside the timed region.  `cpu_baseline` times the CPU oracle
-(oracle/ref_cpu.py = the reference's torch-CPU algorithm) on this box's host cores.
+(VaeGan.init_parameters rule, seed 0), Adam(lr=1e-4).  Headline arithmetic (`dtype`): "bf16x3" = every 5x5
+contraction as three bf16 MFMAs on split-bf16 (hi + lo) operands with fp32 accumulation (16 significant bits per
+operand, ~1e-5 parity with the fp32 reference); `--precision f32` runs every contraction on the exact-fp32 MFMA
+(v_mfma_f32_32x32x2_f32).  Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel family of the
+step (the 5x5 implicit-GEMM convolutions, MFMA-bound): algorithmic FLOPs of its launches / their summed HIP-event
+durations inside the timed region.  `variants` (one GPU only, measured after the headline's timed region, same
+protocol): the exact-f32 mode, per-GPU batches 64 / 128 / 256 and BASELINE config 2 (64x64x3, z=64, batch 128).
+`comm` says what the gradient exchange ran on.  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py = the
+reference's torch-CPU algorithm) on this box's host cores: 2 warm-ups, best of 5, all cores of the affinity mask.
 """
 import argparse
 import json
@@ -31,8 +35,9 @@ import torch.distributed as dist  # noqa: E402
 STEP_GFLOP = {32: 0.6141, 64: 4.0301, 128: 22.2088, 256: 112.0225}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
-CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32",
-              "vp_conv5_gather_bf16x3", "vp_conv5_scatter_bf16x3", "vp_conv5_wgrad_bf16x3"}
+CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32", "vp_conv5_gather_stats_bf16x3", "vp_conv5_scatter_stats_bf16x3",
+              "vp_conv5_gather_bf16x3", "vp_conv5_scatter_bf16x3", "vp_conv5_wgrad_bf16x3",
+              "vp_conv_gather_bf16x3", "vp_conv_wgrad_bf16x3"}
 
 
 def measured_traffic(api_name):
@@ -62,40 +67,215 @@ def parse():
                     help="bf16x3: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate, ~1e-5 parity); "
                          "f32: exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-oracle steps (best is reported) after 2 warm-ups")
+    ap.add_argument("--no-variants", action="store_true", help="skip the f32 / batch-sweep / config-2 variant measurements")
+    ap.add_argument("--variant-steps", type=int, default=20)
+    ap.add_argument("--dp-factored", type=int, choices=[0, 1], default=None,
+                    help="multi-GPU: 1 = exchange the two factors of encoder.fc.0's weight gradient (all-gather) instead of "
+                         "all-reducing the 134 MB product; default: the engine's (VP_DP_FACTORED, on)")
+    ap.add_argument("--dp-enc-tail", type=int, choices=[0, 1], default=None,
+                    help="multi-GPU: 1 = reduce the deep encoder blocks' conv gradients in their own early bucket")
+    ap.add_argument("--dp-overlap", type=int, choices=[0, 1], default=1,
+                    help="multi-GPU: 0 = ONE all-reduce of the whole gradient arena after backward")
     ap.add_argument("--no-settle", action="store_true", help="do exactly --warmup untimed steps (no power-state settling)")
     ap.add_argument("--tags-out", type=str, default="", help="write per-layer conv timings (JSON) to this file")
     return ap.parse_args()
 
 
 def cpu_baseline(args):
-    """The oracle (= reference algorithm on torch CPU) on the host cores: bounded sample."""
+    """The oracle (= reference algorithm on torch CPU) on the host cores: bounded sample.
+    Protocol of BASELINE.md section 4 / SURVEY.md 8d: every core this process may use, 2 warm-up steps, best of 5."""
     from oracle import ref_cpu as O
-    # threads = the CPU share this process may actually use (affinity), capped by VAEPLAY_CPU_THREADS
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = int(os.environ.get("VAEPLAY_CPU_THREADS", min(avail, 16)))
-    torch.set_num_threads(cores)
+    # the CPU share this process really has: the affinity mask of a shared GPU box names all 256 hardware threads while the
+    # container's cgroup quota is 16 CPUs -- 256 torch threads on a 16-CPU quota measured 1.0 images/s (oversubscription)
+    # against 35 with 16.  threads = min(affinity, cgroup quota); both are reported.
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    threads = int(os.environ.get("VAEPLAY_CPU_THREADS", min(avail, quota) if quota else avail))
+    torch.set_num_threads(threads)
     B, C, S, z = args.batch_per_gpu, args.channels, args.img, args.z
     L = O.iter_level_for(S)
     p = O.init_params(C, z, L, seed=0)
     O.require_grad(p)
     opt = O.make_optimizer(p, "adam", 1e-4)
     x, eps = O.synthetic_batch(B, C, S, z)
-    O.train_step(p, opt, x, eps, L)  # warm-up
+    t_w = time.perf_counter()
+    for _ in range(2):
+        O.train_step(p, opt, x, eps, L)  # warm-up
+        if time.perf_counter() - t_w > 30.0:
+            break
     best = float("inf")
+    t_all = time.perf_counter()
+    done = 0
     for _ in range(args.cpu_steps):
         t0 = time.perf_counter()
         O.train_step(p, opt, x, eps, L)
         best = min(best, time.perf_counter() - t0)
-    return {"value": round(B / best, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{args.cpu_steps} timed steps (best) after 1 warm-up, batch {B}, {S}x{S}x{C}, z={z}, "
-                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+        done += 1
+        if time.perf_counter() - t_all > 40.0:      # bounded sample: the default run must finish within minutes
+            break
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(B / best, 2), "unit": "images/sec", "cores": threads, "threads": threads,
+            "host_cores": os.cpu_count(), "affinity_cores": avail, "cgroup_cpus": quota, "cpu_model": model, "kind": "port",
+            "sample": f"best of {done} timed steps after 2 warm-ups, batch {B}, {S}x{S}x{C}, z={z}, "
+                      f"torch {torch.__version__} CPU fp32, {threads} threads = min(affinity mask, cgroup CPU quota) of this box"}
 
 
 SETTLE_STEPS = 200
+
+
+def build_step(B, S, C, z, precision, rank, graph=False):
+    """Model + optimiser + fused plan + resident synthetic batch for one workload."""
+    import vae_play_amd as V
+    from vae_play_amd import engine, optim, parallel
+    torch.manual_seed(0)
+    vae = V.VAE(S, z, C, init_rule=True).to("cuda").train()     # same seed on every rank = replicated weights
+    opt = optim.Adam(vae.parameters(), lr=1e-4)
+    parallel.broadcast_flat_params(opt.flat_param, 0)
+    fused = engine.FusedVAEStep(vae, opt, B, S, C, precision=precision)
+    gx = torch.Generator().manual_seed(1234 + rank)
+    ge = torch.Generator().manual_seed(4321 + rank)
+    x = torch.rand(B, C, S, S, generator=gx).cuda()               # inputs resident in HBM before timing
+    eps = torch.randn(B, z, generator=ge).cuda()
+    if graph:
+        fused.capture()
+    return fused, x, eps
+
+
+def measure(fused, x, eps, steps, untimed, world, graph, overlap=True, tags_out=""):
+    """`untimed` warm-up/settle steps, then EXACTLY `steps` timed steps between barrier + synchronize pairs.
+    HIP events bracket the convolution launches of TWO timed steps only (the first and the middle one), with pre-created
+    events: an event record is a barrier packet on the stream and 52 of them per step cost 0.4-2 ms of pipeline bubbles,
+    which made the figure depend on how many steps were instrumented.  The two instrumented steps also run the SERIAL
+    schedule (weight gradients on the main stream instead of the side stream) so that an event pair times one kernel
+    alone; the other K-2 steps run the concurrent schedule."""
+    for _ in range(untimed):
+        fused.step(x, eps, overlap=overlap)
+    timers = None if graph else {"names": CONV_CALLS, "events": [], "pool": {}, "slot": 0}
+    N_INST = 2
+    if timers is not None:    # create the events (hipEventCreate is not free) outside the timed region
+        for sl in range(N_INST):
+            timers["slot"] = sl
+            fused.step(x, eps, timers, overlap=overlap)
+        torch.cuda.synchronize()
+        timers["events"].clear()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    inst = sorted({0, steps // 2})[:N_INST] if timers is not None else []
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i in inst:
+            timers["slot"] = inst.index(i)
+            loss, recon, kl = fused.step(x, eps, timers, overlap=overlap)
+        else:
+            loss, recon, kl = fused.step(x, eps, None, overlap=overlap)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    final_loss = loss.item()
+    measured = "timed-region"
+    if timers is None:  # graph replay cannot carry events: instrumented eager pass of the same K steps
+        timers = {"names": CONV_CALLS, "events": []}
+        for _ in range(steps):
+            fused.forward_backward(x, eps, timers)
+        torch.cuda.synchronize()
+        measured = "instrumented-pass-after-timed-region"
+    fam = {}
+    for name, tag, flops, e0, e1 in timers["events"]:
+        d = fam.setdefault(name.replace("_stats_bf16x3", "_bf16x3"), [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    if tags_out:
+        per = {}
+        for name, tag, flops, e0, e1 in timers["events"]:
+            d = per.setdefault(tag, [0.0, 0.0, 0])
+            d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+        with open(tags_out, "w") as f:
+            json.dump({k: {"ms": round(v[1] / v[2] * 1e3, 4), "gflop": round(v[0] / v[2] / 1e9, 3),
+                           "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in per.items()}, f, indent=1)
+    n_inst = len(inst) if measured == "timed-region" else steps
+    return {"elapsed": elapsed, "loss": final_loss, "fam": fam, "n_inst": n_inst, "measured": measured}
+
+
+def roofline_of(m, steps, B, S, C, z):
+    fam = m["fam"]
+    dom = max(fam, key=lambda k: fam[k][1])
+    tot_f = sum(v[0] for v in fam.values())
+    tot_t = sum(v[1] for v in fam.values())
+    ach = fam[dom][0] / fam[dom][1] / 1e12
+    is16 = dom.endswith("bf16x3")
+    peak = PEAK_BF16_MFMA_TFLOPS if is16 else PEAK_FP32_MFMA_TFLOPS
+    kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if is16
+             else "igemm_kernel, v_mfma_f32_32x32x2_f32")
+    # the committed PMC passes were taken on the default workload only
+    traffic, traffic_src = measured_traffic(dom) if (S, C, z, B) == (128, 3, 128, 32) else (None, None)
+    return {"bound": "mfma", "kernel": f"{dom} ({kdesc})",
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
+            "traffic_source": traffic_src,
+            "mfma_issue_frac": round(ach * (3 if is16 else 1) / peak, 4),
+            "launches": fam[dom][2], "avg_launch_ms": round(fam[dom][1] / fam[dom][2] * 1e3, 4),
+            "all_conv_families_tflops": round(tot_f / tot_t / 1e12, 2),
+            "conv_share_of_step_time": round(tot_t / m["n_inst"] / (m["elapsed"] / steps), 3),
+            "instrumented_steps": m["n_inst"],
+            "measured": m["measured"]}
+
+
+def comm_record(world, args):
+    """What the gradient exchange ran on (so that a multi-GPU line can be checked from the JSON alone)."""
+    rec = {"backend": None, "world_size_seen": 1, "rccl_version": None, "exchange": "none (one rank)"}
+    try:
+        v = torch.cuda.nccl.version()
+        rec["rccl_version"] = ".".join(str(i) for i in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        pass
+    if world > 1 and dist.is_initialized():
+        rec["backend"] = dist.get_backend()
+        rec["world_size_seen"] = dist.get_world_size()
+        factored = os.environ.get("VP_DP_FACTORED", "1") != "0"
+        tail = os.environ.get("VP_DP_ENC_TAIL", "1") != "0"
+        if not args.dp_overlap:
+            rec["exchange"] = "one SUM all-reduce of the flat gradient arena after backward"
+        else:
+            rec["exchange"] = ("bucketed SUM all-reduce of the flat gradient arena underneath backward (decoder | encoder dense | "
+                               + ("deep encoder convs | " if tail else "") + "rest)"
+                               + ("; encoder.fc.0 weight gradient exchanged as its two factors (2 all-gathers) and contracted locally"
+                                  if factored else ""))
+        rec["dp_factored"], rec["dp_enc_tail"], rec["dp_overlap"] = factored, tail, bool(args.dp_overlap)
+    return rec
 
 
 def main():
@@ -108,6 +288,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
+    if args.dp_factored is not None:
+        os.environ["VP_DP_FACTORED"] = str(args.dp_factored)
+    if args.dp_enc_tail is not None:
+        os.environ["VP_DP_ENC_TAIL"] = str(args.dp_enc_tail)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VP_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the multi-rank path on one GPU
@@ -116,106 +300,24 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
-    import vae_play_amd as V
-    from vae_play_amd import engine, optim, parallel
-
     B, C, S, z = args.batch_per_gpu, args.channels, args.img, args.z
-    torch.manual_seed(0)
-    vae = V.VAE(S, z, C, init_rule=True).to("cuda").train()     # same seed on every rank = replicated weights
-    opt = optim.Adam(vae.parameters(), lr=1e-4)
-    parallel.broadcast_flat_params(opt.flat_param, 0)
-    fused = engine.FusedVAEStep(vae, opt, B, S, C, precision=args.precision)
-    gx = torch.Generator().manual_seed(1234 + rank)
-    ge = torch.Generator().manual_seed(4321 + rank)
-    x = torch.rand(B, C, S, S, generator=gx).cuda()               # inputs resident in HBM before timing
-    eps = torch.randn(B, z, generator=ge).cuda()
-    if args.graph:
-        fused.capture()
+    fused, x, eps = build_step(B, S, C, z, args.precision, rank, args.graph)
 
     # W untimed warm-up steps, then untimed "settle" steps up to SETTLE_STEPS in total: a fresh process starts with the
     # GPU in a low power state and a 0.2-s timed region taken right after a short warm-up measured 4.8-6.6 ms/step
     # for the same binary; after ~1 s of load successive runs agree within 4 % (profiles/r01_c_notes.md).
     # The count is fixed (not time-based) so that every rank of a multi-GPU run executes the same collectives.
     n_settle = max(0, SETTLE_STEPS - args.warmup) if not args.no_settle else 0
-    for _ in range(args.warmup + n_settle):
-        fused.step(x, eps)
+    m = measure(fused, x, eps, args.steps, args.warmup + n_settle, world, args.graph, overlap=bool(args.dp_overlap),
+                tags_out=args.tags_out if rank == 0 else "")
 
-    timers = None if args.graph else {"names": CONV_CALLS, "events": [], "pool": {}, "slot": 0}
-    N_INST = 2      # instrumented steps inside the timed region (first and middle)
-    if timers is not None:    # create the events (hipEventCreate is not free) outside the timed region
-        for sl in range(N_INST):
-            timers["slot"] = sl
-            fused.step(x, eps, timers)
-        torch.cuda.synchronize()
-        timers["events"].clear()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # HIP events bracket the convolution launches of TWO timed steps only (the first and the middle one), with
-    # pre-created events: an event record is a barrier packet on the stream and 52 of them per step cost 0.4-2 ms of
-    # pipeline bubbles, which made the figure depend on how many steps were instrumented (measured: 4.7 ms/step bare,
-    # 5.1-6.6 ms with every step or every 5th step instrumented and events created on the fly).  The two instrumented
-    # steps also run the SERIAL schedule (weight gradients on the main stream instead of the side stream) so that an
-    # event pair times one kernel alone; the other K-2 steps run the concurrent schedule.
-    inst = sorted({0, args.steps // 2})[:N_INST] if timers is not None else []
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i in inst:
-            timers["slot"] = inst.index(i)
-            loss, recon, kl = fused.step(x, eps, timers)
-        else:
-            loss, recon, kl = fused.step(x, eps, None)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-    final_loss = loss.item()
-
-    measured = "timed-region"
-    if timers is None:  # graph replay cannot carry events: instrumented eager pass of the same K steps
-        timers = {"names": CONV_CALLS, "events": []}
-        for _ in range(args.steps):
-            fused.forward_backward(x, eps, timers)
-        torch.cuda.synchronize()
-        measured = "instrumented-pass-after-timed-region"
-
+    out = None
     if rank == 0:
-        fam = {}
-        for name, tag, flops, e0, e1 in timers["events"]:
-            d = fam.setdefault(name, [0.0, 0.0, 0])
-            d[0] += flops
-            d[1] += e0.elapsed_time(e1) * 1e-3
-            d[2] += 1
-        if args.tags_out:
-            per = {}
-            for name, tag, flops, e0, e1 in timers["events"]:
-                d = per.setdefault(tag, [0.0, 0.0, 0])
-                d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
-            with open(args.tags_out, "w") as f:
-                json.dump({k: {"ms": round(v[1] / v[2] * 1e3, 4), "gflop": round(v[0] / v[2] / 1e9, 3),
-                               "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in per.items()}, f, indent=1)
-        n_inst = len(inst) if measured == "timed-region" else args.steps
-        dom = max(fam, key=lambda k: fam[k][1])
-        tot_f = sum(v[0] for v in fam.values())
-        tot_t = sum(v[1] for v in fam.values())
-        ach = fam[dom][0] / fam[dom][1] / 1e12
-        is16 = dom.endswith("bf16x3")
-        peak = PEAK_BF16_MFMA_TFLOPS if is16 else PEAK_FP32_MFMA_TFLOPS
-        kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if is16
-                 else "igemm_kernel, v_mfma_f32_32x32x2_f32")
-        # the committed PMC passes were taken on the default workload only
-        traffic, traffic_src = measured_traffic(dom) if (S, C, z, B) == (128, 3, 128, 32) else (None, None)
-        ips = world * B * args.steps / elapsed
+        ips = world * B * args.steps / m["elapsed"]
         out = {
             "metric": f"images/sec (train step, {S}x{S} VAE)", "value": round(ips, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": n_settle,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": f"networks VAE {S}x{S}x{C} latent={z} train step (fwd+BCE/KL+bwd+allreduce+Adam), "
                                    f"{B} images/GPU, global batch {B * world}", "parallelism": f"dp{world}",
@@ -223,18 +325,40 @@ def main():
                        "precision": args.precision},
             "images_per_sec_per_gpu": round(ips / world, 1),
             "step_algorithmic_tflops_per_gpu": round(ips / world * STEP_GFLOP.get(S, 0.0) / 1e3, 1),
-            "loss": round(final_loss, 4),
-            "roofline": {"bound": "mfma", "kernel": f"{dom} ({kdesc})",
-                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
-                         "traffic_source": traffic_src,
-                         "mfma_issue_frac": round(ach * (3 if is16 else 1) / peak, 4),
-                         "launches": fam[dom][2], "avg_launch_ms": round(fam[dom][1] / fam[dom][2] * 1e3, 4),
-                         "all_conv_families_tflops": round(tot_f / tot_t / 1e12, 2),
-                         "conv_share_of_step_time": round(tot_t / n_inst / (elapsed / args.steps), 3),
-                         "instrumented_steps": n_inst,
-                         "measured": measured},
+            "loss": round(m["loss"], 4),
+            "roofline": roofline_of(m, args.steps, B, S, C, z),
+            "comm": comm_record(world, args),
         }
+    # ---- variants: one GPU only (their collectives would have to match on every rank), after the headline ----------------
+    if world == 1 and not args.no_variants:
+        del fused
+        torch.cuda.empty_cache()
+        todo = []
+        if args.precision != "f32":
+            todo.append(("f32", B, S, C, z))
+        for b2 in (64, 128, 256):
+            if b2 != B:
+                todo.append((args.precision, b2, S, C, z))
+        if (S, C, z, B) != (64, 3, 64, 128):
+            todo.append((args.precision, 128, 64, 3, 64))              # BASELINE.json config 2
+        variants = []
+        for prec, b2, s2, c2, z2 in todo:
+            try:
+                f2, x2, e2 = build_step(b2, s2, c2, z2, prec, rank)
+                m2 = measure(f2, x2, e2, args.variant_steps, 30, 1, False)
+                ips2 = b2 * args.variant_steps / m2["elapsed"]
+                variants.append({
+                    "workload": f"{s2}x{s2}x{c2} z{z2} B{b2}", "precision": prec, "batch_per_gpu": b2,
+                    "steps": args.variant_steps, "ms_per_step": round(m2["elapsed"] / args.variant_steps * 1e3, 4),
+                    "images_per_sec": round(ips2, 1),
+                    "step_algorithmic_tflops": round(ips2 * STEP_GFLOP.get(s2, 0.0) / 1e3, 1),
+                    "roofline": roofline_of(m2, args.variant_steps, b2, s2, c2, z2)})
+                del f2, x2, e2
+                torch.cuda.empty_cache()
+            except Exception as ex:          # a variant must never take the headline line down with it
+                variants.append({"workload": f"{s2}x{s2}x{c2} z{z2} B{b2}", "precision": prec, "error": repr(ex)[:200]})
+        out["variants"] = variants
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

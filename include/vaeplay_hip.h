@@ -104,6 +104,15 @@ int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const 
                            int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream);
 int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, float* big_out,
                             int B, int Hs, int Ws, int Csmall, int Cbig, int stride, vp_stream stream);
+/* First encoder conv (nn.Conv2d(C, 64, k5, s2, p2, bias=False) with C = 1 or 3 image channels, models/networks.py:14 via :55):
+ * its im2col is materialised once per step as split planes [B*Hs*Ws][KC] (KC = vp_im2col5s2_cols(C): 96 / 64), after which the
+ * forward convolution is vp_conv_gather_bf16x3(ks = 1, Cbig = KC) and the weight gradient vp_conv_wgrad_bf16x3(ks = 1) on the
+ * MFMA kernels; the packed weight / the gradient use the same column order (r*GW + q*C + cin) and are converted from / to the
+ * reference layout [64][C][5][5] by the two small kernels below.  x is NCHW (nchw = 1) or NHWC fp32. */
+int vp_im2col5s2_cols(int C);
+int vp_im2col5s2_split_f32(const float* x, void* out_split, int B, int C, int Hb, int Wb, int nchw, vp_stream stream);
+int vp_pack_w_im2col5_split(const float* w_ref, void* out_split, int Cout, int C, vp_stream stream);
+int vp_unpack_dw_im2col5_f32(const float* dw_cols, float* dw_ref, int Cout, int C, vp_stream stream);
 /* Convolution + BatchNorm batch statistics in one call (replaces nn.Conv2d / nn.ConvTranspose2d followed by the statistics
  * pass of nn.BatchNorm2d(momentum=0.9), models/networks.py:14-16,27-28 and :38-40,43-44): the convolution's epilogue emits
  * per-workgroup {pivot, sum(x - pivot), sum((x - pivot)^2)} per output channel from its accumulators and one finaliser
@@ -257,6 +266,14 @@ int vp_half_sqdiff_bwd_f32(const float* a, const float* b, const float* g, float
                            int g_per_row, vp_stream stream);
 /* out[0] = sum x */
 int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream);
+/* loss tail of the composed VAE step (F.binary_cross_entropy(x_tilde, x, reduction='sum') + the KL of
+ * models/networks.py:270 summed over the batch, as train.py:63 does) in two launches: recon = sum of per-pixel BCE,
+ * kl_sum = sum_b kl[b], loss = (recon + kl_sum) * loss_scale (device scalars; loss_scale = 1/B gives the per-image loss). */
+int vp_vae_loss_f32(const float* x_tilde, const float* x, size_t n, const float* kl, int B, float* recon, float* kl_sum,
+                    float* loss, float loss_scale, void* ws, size_t ws_bytes, vp_stream stream);
+/* out = a + b (the two latent heads' input gradients, models/networks.py:76-77 backward) */
+int vp_add_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream);
+
 
 /* ---- optimiser step on a flat arena (train_BE.py:62-64,131; train.py:136-140) --------------- */
 /* torch.optim.Adam semantics (no amsgrad, no weight decay); g is multiplied by grad_scale first

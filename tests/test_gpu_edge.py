@@ -1,0 +1,32 @@
+"""Edge layers (the 3- / 1-channel image side of the first and last convolution) on the matrix cores.
+
+Final conv forward (models/networks.py:100-103, Conv2d(64 -> C, k5, s1, p2) + bias + Sigmoid): the tap-in-N MFMA
+kernel (csrc/narrow.hip conv5s1_tapn_kernel) against a plain torch fp32 reference of the same op on the CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,H,W,nout,act", [(2, 16, 16, 3, 4), (1, 32, 48, 3, 0), (3, 64, 32, 1, 4), (2, 128, 128, 3, 4), (1, 256, 256, 1, 4)])
+def test_final_conv_tapn_matches_torch(B, H, W, nout, act):
+    from vae_play_amd import ops
+    g = torch.Generator().manual_seed(7 + H + nout)
+    x = torch.rand(B, 64, H, W, generator=g) * 2.0 - 0.3       # post-ReLU-like range with some negatives
+    w = (torch.rand(nout, 64, 5, 5, generator=g) - 0.5) * 0.1
+    b = torch.rand(nout, generator=g) - 0.5
+    ref = F.conv2d(x, w, b, padding=2)
+    if act == 4:
+        ref = torch.sigmoid(ref)
+    xd = ops.channels_last(x.cuda())
+    p0, _ = ops.pack_w5(w.cuda(), True, False)
+    y = ops.conv5_gather(xd, p0, b.cuda(), 1, act)
+    assert y.shape == ref.shape
+    # split-bf16 contraction: 16 significant bits per operand, fp32 accumulation
+    assert_close(y.cpu(), ref, 3e-5, f"final conv tap-in-N {B}x{H}x{W}x{nout}")
+    # image borders are where the halo patch is zero-filled: check them on their own
+    for sl in ((..., 0, slice(None)), (..., H - 1, slice(None)), (..., slice(None), 0), (..., slice(None), W - 1)):
+        assert_close(y.cpu()[sl], ref[sl], 1e-4, "border")

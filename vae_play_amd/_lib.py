@@ -48,6 +48,10 @@ SIGNATURES = {
     "vp_conv_wgrad_bf16x3": (c_int, [P, P, P] + [c_int] * 9 + [P, c_size_t, P]),
     "vp_conv5_gather_bf16x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_scatter_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_im2col5s2_cols": (c_int, [c_int]),
+    "vp_im2col5s2_split_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_pack_w_im2col5_split": (c_int, [P, P, c_int, c_int, P]),
+    "vp_unpack_dw_im2col5_f32": (c_int, [P, P, c_int, c_int, P]),
     "vp_conv5_stats_workspace_bytes": (c_size_t, [c_int] * 7),
     "vp_conv5_gather_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_conv5_scatter_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
@@ -83,6 +87,8 @@ SIGNATURES = {
     "vp_bce_bwd_f32": (c_int, [P, P, P, c_float, P, c_size_t, P]),
     "vp_bce_sigmoid_bwd_f32": (c_int, [P, P, c_float, P, c_size_t, P]),
     "vp_sum_f32": (c_int, [P, c_size_t, P, P, c_size_t, P]),
+    "vp_vae_loss_f32": (c_int, [P, P, c_size_t, P, c_int, P, P, P, c_float, P, c_size_t, P]),
+    "vp_add_f32": (c_int, [P, P, P, c_size_t, P]),
     "vp_global_avgpool_fwd_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
     "vp_global_avgpool_bwd_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
     "vp_softmax_rows_fwd_f32": (c_int, [P, P, c_int, c_int, P]),

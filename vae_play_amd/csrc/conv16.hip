@@ -144,6 +144,63 @@ int pack_w5_f32_launch(const float* w, float* p0, float* p1, int Cs, int Cb, hip
   return pack_w5_launch<false>(w, p0, p1, Cs, Cb, s, "vp_pack_w_f32", 0, nt);
 }
 
+
+// ---- first encoder conv (1 or 3 image channels, 5x5, stride 2) as a 1x1 convolution over a materialised im2col -------------
+// K = 25*C = 75 is hostile to the implicit GEMM (scalar gathers, >= 90 % padded tiles: 47 us forward on the exact-f32 kernel,
+// 152 us for the weight gradient on a VALU kernel at B = 32, 128x128).  The image is tiny (6 MB), so its im2col is simply
+// written out once per step as split planes Xcol[pixel][KC] (KC = 96 for 3 channels: five kernel rows x 16 columns, of which
+// 15 = (q, cin) are used; 50 MB) and BOTH the forward convolution and the weight gradient become 1x1 layers on the split-bf16
+// MFMA kernels (vp_conv_gather_bf16x3 / vp_conv_wgrad_bf16x3 with ks = 1).  Column of (r, q, cin) = r*GW + q*C + cin.
+static inline int im2col5_gw(int C) { return C == 3 ? 16 : (C == 1 ? 8 : 0); }
+static inline int im2col5_kc(int C) { const int g = im2col5_gw(C); return g ? ((5 * g + 31) / 32) * 32 : 0; }
+
+template <int C>
+__global__ void __launch_bounds__(256) im2col5s2_split_kernel(const float* __restrict__ x, u16_t* __restrict__ out, int B, int Hb, int Wb,
+                                                              int Hs, int Ws, int nchw) {
+  // blockIdx.x = output row (b, hs); a thread = (ws, 8-column group): 16-B stores into both planes, every division by a constant
+  constexpr int GW = C == 3 ? 16 : 8, KC = ((5 * GW + 31) / 32) * 32, G = KC / 8;
+  const size_t npix = (size_t)B * Hs * Ws, n = npix * KC;
+  const int row = blockIdx.x, b = row / Hs, hs = row - b * Hs;
+  for (int i = threadIdx.x; i < Ws * G; i += blockDim.x) {
+    const int ws = i / G, c0 = (i - ws * G) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = c0 + j, r = col / GW, rem = col - r * GW;
+      const int q = rem / C, cin = rem - q * C;
+      const int h = 2 * hs - 2 + r, w_ = 2 * ws - 2 + q;
+      const bool ok = r < 5 && q < 5 && h >= 0 && h < Hb && w_ >= 0 && w_ < Wb;
+      v[j] = ok ? (nchw ? x[(((size_t)b * C + cin) * Hb + h) * Wb + w_] : x[(((size_t)b * Hb + h) * Wb + w_) * C + cin]) : 0.f;
+    }
+    const size_t o = ((size_t)row * Ws + ws) * KC + c0;
+    store_split4(out, n, o, v[0], v[1], v[2], v[3]);
+    store_split4(out, n, o + 4, v[4], v[5], v[6], v[7]);
+  }
+}
+
+// w_ref [Cout][C][5][5] -> split planes [Cout][KC] in the im2col column order (zero columns where no tap lives)
+__global__ void pack_w_im2col5_split_kernel(const float* __restrict__ w, u16_t* __restrict__ out, int Cout, int C, int GW, int KC) {
+  const size_t n = (size_t)Cout * KC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i / KC), col = (int)(i - (size_t)co * KC);
+    const int r = col / GW, rem = col - r * GW, q = rem / C, cin = rem - q * C;
+    const float v = (r < 5 && q < 5) ? w[(((size_t)co * C + cin) * 5 + r) * 5 + q] : 0.f;
+    u16_t h, l;
+    split_f32(v, h, l);
+    out[i] = h;
+    out[n + i] = l;
+  }
+}
+
+// dW in im2col column order [Cout][KC] -> reference layout [Cout][C][5][5]
+__global__ void unpack_dw_im2col5_kernel(const float* __restrict__ dwc, float* __restrict__ dw, int Cout, int C, int GW, int KC) {
+  const size_t n = (size_t)Cout * C * 25;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % 5), r = (int)((i / 5) % 5), cin = (int)((i / 25) % C), co = (int)(i / ((size_t)25 * C));
+    dw[i] = dwc[(size_t)co * KC + r * GW + q * C + cin];
+  }
+}
+
 }  // namespace vp
 
 using namespace vp;
@@ -504,6 +561,37 @@ int vp_conv5_scatter_stats_bf16x3(const void* small_split, const void* w_p1_spli
                                 (float*)ws);
   if (rc) return rc;
   return stats_finish(sp, (const float*)ws, eps, momentum, mean, rstd, running_mean, running_var, stream);
+}
+
+}
+
+extern "C" {
+
+int vp_im2col5s2_cols(int C) { return im2col5_kc(C); }
+
+int vp_im2col5s2_split_f32(const float* x, void* out_split, int B, int C, int Hb, int Wb, int nchw, vp_stream stream) {
+  VP_REQUIRE(x && out_split && B > 0 && Hb > 0 && Wb > 0 && Hb % 2 == 0 && Wb % 2 == 0, "vp_im2col5s2_split_f32: bad arguments");
+  VP_REQUIRE(C == 1 || C == 3, "vp_im2col5s2_split_f32: 1 or 3 image channels");
+  const dim3 grid((unsigned)(B * (Hb / 2)));
+  if (C == 3) hipLaunchKernelGGL((im2col5s2_split_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, x, (u16_t*)out_split, B, Hb, Wb, Hb / 2, Wb / 2, nchw);
+  else hipLaunchKernelGGL((im2col5s2_split_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, (u16_t*)out_split, B, Hb, Wb, Hb / 2, Wb / 2, nchw);
+  return check_launch("vp_im2col5s2_split_f32");
+}
+
+int vp_pack_w_im2col5_split(const float* w_ref, void* out_split, int Cout, int C, vp_stream stream) {
+  VP_REQUIRE(w_ref && out_split && Cout > 0 && (C == 1 || C == 3), "vp_pack_w_im2col5_split: bad arguments");
+  const int KC = im2col5_kc(C), GW = im2col5_gw(C);
+  hipLaunchKernelGGL(pack_w_im2col5_split_kernel, dim3(grid_for((size_t)Cout * KC, 256)), dim3(256), 0, (hipStream_t)stream, w_ref,
+                     (u16_t*)out_split, Cout, C, GW, KC);
+  return check_launch("vp_pack_w_im2col5_split");
+}
+
+int vp_unpack_dw_im2col5_f32(const float* dw_cols, float* dw_ref, int Cout, int C, vp_stream stream) {
+  VP_REQUIRE(dw_cols && dw_ref && Cout > 0 && (C == 1 || C == 3), "vp_unpack_dw_im2col5_f32: bad arguments");
+  const int KC = im2col5_kc(C), GW = im2col5_gw(C);
+  hipLaunchKernelGGL(unpack_dw_im2col5_kernel, dim3(grid_for((size_t)Cout * C * 25, 256)), dim3(256), 0, (hipStream_t)stream, dw_cols, dw_ref,
+                     Cout, C, GW, KC);
+  return check_launch("vp_unpack_dw_im2col5_f32");
 }
 
 }

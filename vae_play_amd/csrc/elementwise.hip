@@ -129,6 +129,27 @@ __global__ void reduce_final_kernel(const float* __restrict__ part, int nblocks,
 }
 
 
+// loss tail of the VAE step in one launch: recon = sum of the BCE partials, kl_sum = sum_b kl[b], loss = recon + kl_sum
+// (replaces two reduce_final launches, a partial launch over B values and an ATen add on the benchmarked path)
+__global__ void vae_loss_final_kernel(const float* __restrict__ part, int nblocks, const float* __restrict__ kl, int B,
+                                      float* __restrict__ recon, float* __restrict__ kl_sum, float* __restrict__ loss, float loss_scale) {
+  double a = 0.0, k = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) a += (double)part[i];
+  for (int i = threadIdx.x; i < B; i += 64) k += (double)kl[i];
+  a = wave_sum_d(a);
+  k = wave_sum_d(k);
+  if (threadIdx.x == 0) {
+    recon[0] = (float)a;
+    kl_sum[0] = (float)k;
+    loss[0] = ((float)a + (float)k) * loss_scale;   // fp32 add of the two rounded sums, then the caller's 1/B (an exact scaling
+                                                    // for power-of-two batches; torch's (recon + kl) / B otherwise differs by <= 1 ulp)
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+
 // ---- 0.5*(a-b)^2: per element (VaeGan.loss "nle", models/networks.py:267) and summed per row (":273", the
 // feature-matching term between discriminator layers) ------------------------------------------------------
 __global__ void half_sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
@@ -573,6 +594,25 @@ int vp_bce_sum_f32(const float* p, const float* t, size_t n, float* out, void* w
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, (int)nb, out);
   return check_launch("vp_bce_sum_f32(final)");
+}
+
+int vp_vae_loss_f32(const float* x_tilde, const float* x, size_t n, const float* kl, int B, float* recon, float* kl_sum, float* loss,
+                    float loss_scale, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(x_tilde && x && kl && recon && kl_sum && loss && ws && n > 0 && B > 0, "vp_vae_loss_f32: bad arguments");
+  const unsigned nb = reduce_blocks(n);
+  if (ws_bytes < nb * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_vae_loss_f32: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((reduce_partial_kernel<0>), dim3(nb), dim3(256), 0, s, x_tilde, x, n, (float*)ws);
+  int rc = check_launch("vp_vae_loss_f32(partial)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(vae_loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, (int)nb, kl, B, recon, kl_sum, loss, loss_scale);
+  return check_launch("vp_vae_loss_f32(final)");
+}
+
+int vp_add_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream) {
+  VP_REQUIRE(a && b && out && n > 0, "vp_add_f32: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  return check_launch("vp_add_f32");
 }
 
 int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream) {

@@ -360,18 +360,21 @@ __device__ __forceinline__ void split8(const vp_f32x4& a, const vp_f32x4& b, bf1
   }
 }
 
+// 8 waves per workgroup (two per SIMD: the patch loads, the MFMAs and the P stores of different waves overlap -- with four
+// waves they ran back to back: 32 + 40 + 22 us of a 102-us kernel), workgroups persistent over the tile list so that the
+// weight fragments are loaded and split once per workgroup.
 template <int NOUT>
-__global__ void __launch_bounds__(256, 1) conv5s1_tapn_kernel(const float* __restrict__ in, const float* __restrict__ w,
+__global__ void __launch_bounds__(512, 2) conv5s1_tapn_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                              int H, int W, int act) {
+                                                              int H, int W, int tiles_x, int tiles_per_img, int ntiles, int act) {
   constexpr int C = 64, T = 16, HALO = T + 4, NPIX = HALO * HALO;     // 400 patch pixels
   constexpr int NCOL = 25 * NOUT, NT = (NCOL + 31) / 32;               // 75 -> 3 column tiles, 25 -> 1
   constexpr int PITCH = 32 * NT + 1;                                   // odd word pitch
   constexpr int MT = (NPIX + 31) / 32;                                 // 13 row tiles
+  constexpr int NWAVE = 8;
   __shared__ float P[NPIX * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h0 = blockIdx.y * T, w0 = blockIdx.x * T;
 
   // B fragments: row (32 jt + li) of the [NCOL][C] weight view, channels 32*lh + 8*s .. +7 for MFMA k-step s
   bf16x8_e bh[NT][4], bl[NT][4];
@@ -390,71 +393,77 @@ __global__ void __launch_bounds__(256, 1) conv5s1_tapn_kernel(const float* __res
     }
   }
 
-  auto load_tile = [&](int t, vp_f32x4 (&raw)[8]) {
-    const int pi = 32 * t + li;
-    const int py = pi / HALO, px = pi - py * HALO;
-    const int gh = h0 + py - 2, gw = w0 + px - 2;
-    const bool ok = pi < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W;
-    const float* q = in + ((size_t)(b * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * C + 32 * lh;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+    const int h0 = (rem / tiles_x) * T, w0 = (rem % tiles_x) * T;
+    auto load_tile = [&](int t, vp_f32x4 (&raw)[8]) {
+      const int pi = 32 * t + li;
+      const int py = pi / HALO, px = pi - py * HALO;
+      const int gh = h0 + py - 2, gw = w0 + px - 2;
+      const bool ok = pi < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      const float* q = in + ((size_t)(b * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * C + 32 * lh;
 #pragma unroll
-    for (int v = 0; v < 8; ++v) raw[v] = ok ? ld4(q + 4 * v) : zero4();
-  };
-
-  vp_f32x4 cur[8], nxt[8];
-  if (wave < MT) load_tile(wave, cur);
-  for (int t = wave; t < MT; t += 4) {
-    const bool more = t + 4 < MT;
-    if (more) load_tile(t + 4, nxt);
-    f32x16_e acc[NT];
+      for (int v = 0; v < 8; ++v) raw[v] = ok ? ld4(q + 4 * v) : zero4();
+    };
+    vp_f32x4 cur[8], nxt[8];
+    if (wave < MT) load_tile(wave, cur);
+    for (int t = wave; t < MT; t += NWAVE) {
+      const bool more = t + NWAVE < MT;
+      if (more) load_tile(t + NWAVE, nxt);
+      f32x16_e acc[NT];
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+      for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8_e ah, al;
-      split8(cur[2 * s], cur[2 * s + 1], ah, al);
+      for (int s = 0; s < 4; ++s) {
+        bf16x8_e ah, al;
+        split8(cur[2 * s], cur[2 * s + 1], ah, al);
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[jt][s], acc[jt], 0, 0, 0);
-        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[jt][s], acc[jt], 0, 0, 0);
-        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[jt][s], acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < NT; ++jt) {
+          acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[jt][s], acc[jt], 0, 0, 0);
+          acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[jt][s], acc[jt], 0, 0, 0);
+          acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[jt][s], acc[jt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < NPIX) P[row * PITCH + 32 * jt + li] = acc[jt][r];
+        }
+      if (more) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) cur[v] = nxt[v];
       }
     }
+    __syncthreads();
+    if (tid < T * T) {
+      const int tx = tid % T, ty = tid / T;
+      const int h = h0 + ty, ww = w0 + tx;
+      float sum[NOUT];
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+      for (int n = 0; n < NOUT; ++n) sum[n] = bias ? bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < NPIX) P[row * PITCH + 32 * jt + li] = acc[jt][r];
+      for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          const float* pp = &P[((ty + r) * HALO + tx + q) * PITCH + r * 5 + q];
+#pragma unroll
+          for (int n = 0; n < NOUT; ++n) sum[n] += pp[n * 25];
+        }
+      if (h < H && ww < W) {
+        float* o = out + ((size_t)(b * H + h) * W + ww) * NOUT;
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+          float v = sum[n];
+          if (act == ACT_SIGMOID) v = 1.f / (1.f + __builtin_expf(-v));
+          o[n] = v;
+        }
       }
-    if (more) {
-#pragma unroll
-      for (int v = 0; v < 8; ++v) cur[v] = nxt[v];
     }
-  }
-  __syncthreads();
-  const int tx = tid % T, ty = tid / T;
-  const int h = h0 + ty, ww = w0 + tx;
-  float sum[NOUT];
-#pragma unroll
-  for (int n = 0; n < NOUT; ++n) sum[n] = bias ? bias[n] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 5; ++r)
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const float* pp = &P[((ty + r) * HALO + tx + q) * PITCH + r * 5 + q];
-#pragma unroll
-      for (int n = 0; n < NOUT; ++n) sum[n] += pp[n * 25];
-    }
-  if (h < H && ww < W) {
-    float* o = out + ((size_t)(b * H + h) * W + ww) * NOUT;
-#pragma unroll
-    for (int n = 0; n < NOUT; ++n) {
-      float v = sum[n];
-      if (act == ACT_SIGMOID) v = 1.f / (1.f + __builtin_expf(-v));
-      o[n] = v;
-    }
+    __syncthreads();      // P is rewritten by the next tile
   }
 }
 
@@ -469,8 +478,10 @@ int narrow_gather_launch(const float* big, const float* w_p0, const float* bias,
   // 64 input channels (every decoder of models/networks.py ends in 64): the matrix-core kernel; VP_TAPN=0 keeps the VALU kernel
   static const bool tapn = [] { const char* e = getenv("VP_TAPN"); return !e || atoi(e) != 0; }();
   if (tapn && g.Cb == 64 && ((uintptr_t)big & 15) == 0 && ((uintptr_t)w_p0 & 15) == 0) {
-    if (g.Cs == 3) hipLaunchKernelGGL((conv5s1_tapn_kernel<3>), grid, dim3(256), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, act);
-    else hipLaunchKernelGGL((conv5s1_tapn_kernel<1>), grid, dim3(256), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, act);
+    const int tiles_x = (g.Ws + 15) / 16, tiles_per_img = tiles_x * ((g.Hs + 15) / 16), ntiles = tiles_per_img * g.B;
+    const dim3 pgrid((unsigned)(ntiles < 256 ? ntiles : 256));          // one persistent workgroup per CU
+    if (g.Cs == 3) hipLaunchKernelGGL((conv5s1_tapn_kernel<3>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act);
+    else hipLaunchKernelGGL((conv5s1_tapn_kernel<1>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act);
     return check_launch("conv5s1_tapn");
   }
   if (g.Cs == 3)
@@ -532,7 +543,8 @@ int narrow_wgrad_launch(const float* big, const float* small, float* dw_ref, con
 
 int slab_reduce_launch(const float* slab, float* dw_ref, int Cs, int Cb, int nsplit, hipStream_t s, int nt) {
   const size_t cc = (size_t)Cs * Cb, per = cc * nt;
-  if (cc >= 4096 && nt <= 25)
+  // (a 1x1 layer has one tap: the wide kernel would leave three of its four tap groups idle and walk every split serially)
+  if (cc >= 4096 && nt <= 25 && !(nt == 1 && nsplit > 16))
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((cc + 63) / 64)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);
   else
     hipLaunchKernelGGL(slab_reduce_deep_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, s, slab, dw_ref, Cs, Cb, nsplit, nt);

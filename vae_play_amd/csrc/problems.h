@@ -481,7 +481,9 @@ inline int wgrad_nsplit(const ConvGeom& g) {
   long maxs = (K + 511) / 512;  // keep >= 16 K-tiles of 32 per split
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
-  const long cap = tiny ? 512 : 64;
+  // a 1x1 layer whose whole weight is one or two tiles (the first encoder conv on its im2col: 64 x 96, 131 072 pixels at
+  // B = 32) offers no tap parallelism at all: split the pixels up to 256 ways
+  const long cap = tiny ? 512 : (tiles <= 2 ? 256 : 64);
   if (s > cap) s = cap;
   return (int)s;
 }

@@ -223,6 +223,7 @@ class FusedVAEStep:
         enc_ch = [C] + [blk.conv.weight.shape[0] for blk in enc.conv]
         sp = [S // (2 ** i) for i in range(L + 1)]
         enc16 = [use16(enc_ch[i], enc_ch[i + 1]) for i in range(L)]
+        enc0_cols = x3 and C in (1, 3) and enc_ch[1] % 8 == 0 and os.environ.get("VP_ENC0_IM2COL", "1") != "0"
         enc_in = [x_nhwc]        # fp32 inputs (None when only the split copy exists)
         enc_in_s = [None]        # split inputs
         enc_rec = []
@@ -234,7 +235,18 @@ class FusedVAEStep:
             c = self._buf(f"enc{i}.c", n_out)
             fl = 50.0 * B * Hs * Hs * Cin * Cout
             conv = None
-            if enc16[i]:
+            if i == 0 and enc0_cols:
+                # first conv (1 or 3 image channels): im2col written once as split planes, then a 1x1 layer on the MFMA kernels
+                KC = lib.vp_im2col5s2_cols(Cin)
+                xcol = self._sbuf("enc0.xcol", B * Hs * Hs * KC)
+                w0s = self._sbuf("enc0.w0s", Cout * KC)
+                self._enc0 = (xcol, KC)
+                fwd.add("vp_im2col5s2_split_f32", P(self.x_nchw), P(xcol), B, Cin, S, S, 1)
+                fwd.add("vp_pack_w_im2col5_split", P(blk.conv.weight), P(w0s), Cout, Cin)
+                fwd.add("vp_conv_gather_bf16x3", P(xcol), P(w0s), None, P(c), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, _ACT_NONE,
+                        flops=fl, tag="enc0.fwd")
+                p1 = None
+            elif enc16[i]:
                 p0 = self._sbuf(f"enc{i}.p0s", Cout * 25 * Cin)
                 p1 = self._sbuf(f"enc{i}.p1s", Cin * 25 * Cout)
                 pack(blk.conv.weight, p0, p1, Cout, Cin, True, first=(i == 0))
@@ -335,8 +347,9 @@ class FusedVAEStep:
         self.kl_sum = self._buf("kl_sum", 1)
         n_pix = B * S * S * C
         ws_red = self._ws("red.ws", lib.vp_reduce_workspace_bytes(n_pix))
-        fwd.add("vp_bce_sum_f32", P(xt_nhwc), P(x_nhwc), n_pix, P(self.recon), P(ws_red), ws_red.numel() * 4)
-        fwd.add("vp_sum_f32", P(self.kl), B, P(self.kl_sum), P(ws_red), ws_red.numel() * 4)
+        self._loss_num = self._buf("loss_num", 1)
+        fwd.add("vp_vae_loss_f32", P(xt_nhwc), P(x_nhwc), n_pix, P(self.kl), B, P(self.recon), P(self.kl_sum), P(self._loss_num),
+                1.0 / B, P(ws_red), ws_red.numel() * 4)
         self.xt_nhwc = xt_nhwc
         self.x_tilde = xt_nhwc.view(B, S, S, C).permute(0, 3, 1, 2)  # logical NCHW, channels_last memory
 
@@ -416,8 +429,8 @@ class FusedVAEStep:
             bwd.add("vp_gemm_f32", P(dsrc), 1, Z, P(hb), 1, 1024, P(grad_of(lin.weight)), 1024, None, Z, 1024, B, 2, P(ws_g1), wsn)
             bwd.add("vp_colsum_f32", P(dsrc), P(grad_of(lin.bias)), B, Z, P(ws_cs2), ws_cs2.numel() * 4)
             bwd.add("vp_gemm_f32", P(dsrc), Z, 1, P(lin.weight), 1, 1024, P(dst), 1024, None, B, 1024, Z, 1, P(ws_g1), wsn)
-        self._dhb = (dhb_a, dhb_b)
-        bwd_b = _Plan()  # continues after the tiny add of the two head gradients
+        bwd.add("vp_add_f32", P(dhb_a), P(dhb_b), P(dhb_a), B * 1024)     # d hb = dgrad(mu head) + dgrad(logvar head)
+        bwd_b = _Plan()
         self._bwd_a = bwd
         bwd = bwd_b
         dh = self._buf("g.dh", B * 1024)
@@ -441,7 +454,18 @@ class FusedVAEStep:
             blk, Cin, Cout, Hs, p1, c, mean, rstd, ws = enc_rec[i]
             R = B * Hs * Hs
             fl = 50.0 * B * Hs * Hs * Cin * Cout
-            if enc16[i]:
+            if i == 0 and enc0_cols:
+                xcol, KC = self._enc0
+                k = next_gs(bwd)
+                gS = gS2[k]
+                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)        # gS = d c_0 (split)
+                dwc = self._buf("enc0.dwc", Cout * KC)
+                ws0 = self._ws("enc0.wgws", lib.vp_conv_wgrad_bf16x3_workspace_bytes(B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1))
+                gs_last[k] = side_slot()
+                bwd.add("vp_conv_wgrad_bf16x3", P(xcol), P(gS), P(dwc), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, P(ws0), ws0.numel() * 4,
+                        flops=fl, tag="enc0.wgrad", side=gs_last[k])
+                bwd.add("vp_unpack_dw_im2col5_f32", P(dwc), P(grad_of(blk.conv.weight)), Cout, Cin, side=side_slot())
+            elif enc16[i]:
                 k = next_gs(bwd)
                 gS = gS2[k]
                 bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)        # gS = d c_i (split)
@@ -497,7 +521,6 @@ class FusedVAEStep:
                 torch.cuda.current_stream().wait_stream(side[0])
             on_decoder_grads()
         self._bwd_a.run(s, timers)
-        self._dhb[0].add_(self._dhb[1])          # d hb = dgrad(mu head) + dgrad(logvar head)  (B x 1024)
         if on_fc_wgrad is not None:
             self._bwd_b.run(s, timers, 0, self._bwd_b_fc_wgrad)
             on_fc_wgrad()                                     # computes the fc.0 weight gradient from gathered factors
@@ -515,7 +538,6 @@ class FusedVAEStep:
             self._bwd_b.run(s, timers, self._bwd_b_dense_done, side=side)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side[0])
-        torch.add(self.recon, self.kl_sum, out=self._loss_num)
 
     def _side_ctx(self):
         """(side stream, its events, fork event) when weight gradients run concurrently (bf16x3 plans, VP_SIDE_WGRAD != 0)."""
@@ -528,11 +550,10 @@ class FusedVAEStep:
     def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None,
                          on_dense_grads=None, on_fc_wgrad=None, after_forward=None, on_encoder_tail=None):
         """Gradients of (BCE_sum + KL_sum)/B land in the optimiser's flat gradient arena.
-        Returns (loss, recon, kl) as device scalars (no host sync).  ``timers`` =
+        Returns (loss, recon, kl) as device scalars (no host sync).  They are the plan's static output buffers (like the
+        outputs of a captured graph): the next step overwrites them, so read or copy them before stepping again.  ``timers`` =
         {"names": set of entry points, "events": []} brackets those launches with HIP events
         (eager mode only)."""
-        if not hasattr(self, "_loss_num"):
-            self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
         self._bind_inputs(x, eps)
         if self._graph is not None and timers is None and on_decoder_grads is None and on_dense_grads is None \
                 and on_fc_wgrad is None and after_forward is None and on_encoder_tail is None:
@@ -541,7 +562,7 @@ class FusedVAEStep:
             self._launch_all(timers, on_decoder_grads, on_dense_grads, on_fc_wgrad, after_forward, on_encoder_tail)
         # BatchNorm num_batches_tracked is advanced lazily in sync_counters()
         self._steps_since_sync = getattr(self, "_steps_since_sync", 0) + 1
-        return self._loss_num / self.B, self.recon, self.kl_sum
+        return self._loss_num, self.recon, self.kl_sum     # (loss per image, recon sum, KL sum): device scalars of the plan
 
     def _bind_inputs(self, x: torch.Tensor, eps: torch.Tensor) -> None:
         """Point the launches that consume the batch at the caller's tensors (fp32, contiguous, on this device, right shape:
@@ -679,8 +700,6 @@ class FusedVAEStep:
 
     def capture(self, warmup: int = 2):
         """Capture forward+backward into a hipGraph (torch.cuda.CUDAGraph) and replay it from then on."""
-        if not hasattr(self, "_loss_num"):
-            self._loss_num = torch.empty(1, dtype=torch.float32, device=self.dev)
         self._bind_inputs(self.x_nchw, self.eps)      # the graph's nodes must read the static buffers
         # warm-up and capture execute the step: keep the BatchNorm running buffers unchanged by them
         saved = [(m, m.running_mean.clone(), m.running_var.clone()) for m in self._bn_mods]
