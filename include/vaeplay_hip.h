@@ -104,6 +104,11 @@ int vp_conv5_gather_bf16x3(const void* big_split, const void* w_p0_split, const 
                            int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int act, vp_stream stream);
 int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, float* big_out,
                             int B, int Hs, int Ws, int Csmall, int Cbig, int stride, vp_stream stream);
+/* Final conv + bias + sigmoid (nn.Conv2d(64, C, k5, s1, p2) + nn.Sigmoid, models/networks.py:100-103, C = 1 or 3) in split-bf16
+ * arithmetic on the matrix cores: the 25 taps x C outputs are the MFMA column dimension ("tap-in-N", csrc/narrow.hip); fp32 NHWC
+ * input (split into bf16 hi/lo in registers) and the fp32 packed weights P0 [C][25][64] of vp_pack_w5_f32, fp32 output. */
+int vp_conv5_smallout_bf16x3(const float* big, const float* w_p0, const float* bias, float* small_out, int B, int H, int W,
+                             int Cbig, int Csmall, int act, vp_stream stream);
 /* First encoder conv (nn.Conv2d(C, 64, k5, s2, p2, bias=False) with C = 1 or 3 image channels, models/networks.py:14 via :55):
  * its im2col is materialised once per step as split planes [B*Hs*Ws][KC] (KC = vp_im2col5s2_cols(C): 96 / 64), after which the
  * forward convolution is vp_conv_gather_bf16x3(ks = 1, Cbig = KC) and the weight gradient vp_conv_wgrad_bf16x3(ks = 1) on the

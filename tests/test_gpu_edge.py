@@ -21,9 +21,14 @@ def test_final_conv_tapn_matches_torch(B, H, W, nout, act):
     ref = F.conv2d(x, w, b, padding=2)
     if act == 4:
         ref = torch.sigmoid(ref)
+    from vae_play_amd import _lib
     xd = ops.channels_last(x.cuda())
     p0, _ = ops.pack_w5(w.cuda(), True, False)
-    y = ops.conv5_gather(xd, p0, b.cuda(), 1, act)
+    bd = b.cuda()
+    y = ops.empty_cl(B, nout, H, W, xd)
+    _lib.call("vp_conv5_smallout_bf16x3", ops._p(xd), ops._p(p0), ops._p(bd), ops._p(y), B, H, W, 64, nout, act, ops._stream())
+    # the exact-fp32 entry point keeps its VALU kernel: the two arithmetics agree to the split's 16 bits
+    assert_close(y.cpu(), ops.conv5_gather(xd, p0, bd, 1, act).cpu(), 3e-5, "tap-in-N vs exact-f32 kernel")
     assert y.shape == ref.shape
     # split-bf16 contraction: 16 significant bits per operand, fp32 accumulation
     assert_close(y.cpu(), ref, 3e-5, f"final conv tap-in-N {B}x{H}x{W}x{nout}")

@@ -13,13 +13,22 @@ x = ops.channels_last(torch.rand(B, 64, 128, 128, device="cuda"))
 w = (torch.rand(3, 64, 5, 5, device="cuda") - 0.5) * 0.1
 b = torch.zeros(3, device="cuda")
 p0, _ = ops.pack_w5(w, True, False)
-for _ in range(5):
-    y = ops.conv5_gather(x, p0, b, 1, 4)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(50):
-    y = ops.conv5_gather(x, p0, b, 1, 4)
-e1.record()
-torch.cuda.synchronize()
-print(f"final conv fwd B={B} VP_TAPN={os.environ.get('VP_TAPN', '1')}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
+from vae_play_amd import _lib  # noqa: E402
+y = ops.empty_cl(B, 3, 128, 128, x)
+
+
+def tapn():
+    _lib.call("vp_conv5_smallout_bf16x3", ops._p(x), ops._p(p0), ops._p(b), ops._p(y), B, 128, 128, 64, 3, 4, ops._stream())
+
+
+for name, fn in (("tap-in-N MFMA (bf16x3)", tapn), ("VALU (exact f32)", lambda: ops.conv5_gather(x, p0, b, 1, 4))):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"final conv fwd B={B} {name}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")

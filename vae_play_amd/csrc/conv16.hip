@@ -594,4 +594,14 @@ int vp_unpack_dw_im2col5_f32(const float* dw_cols, float* dw_ref, int Cout, int 
   return check_launch("vp_unpack_dw_im2col5_f32");
 }
 
+
+int vp_conv5_smallout_bf16x3(const float* big, const float* w_p0, const float* bias, float* small_out, int B, int H, int W, int Cbig,
+                             int Csmall, int act, vp_stream stream) {
+  VP_REQUIRE(big && w_p0 && small_out && B > 0 && H > 0 && W > 0, "vp_conv5_smallout_bf16x3: bad arguments");
+  VP_REQUIRE(((uintptr_t)big & 15) == 0 && ((uintptr_t)w_p0 & 15) == 0, "vp_conv5_smallout_bf16x3: operands must be 16-byte aligned");
+  const ConvGeom g = make_geom(B, H, W, Csmall, Cbig, 1);
+  VP_REQUIRE(tapn_gather_applicable(g, act), "vp_conv5_smallout_bf16x3: needs 64 input channels, 1 or 3 outputs, act none|sigmoid");
+  return tapn_gather_launch(big, w_p0, bias, small_out, g, act, (hipStream_t)stream);
+}
+
 }

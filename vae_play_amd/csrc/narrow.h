@@ -6,6 +6,8 @@
 namespace vp {
 bool narrow_gather_applicable(const ConvGeom& g, int act);
 int narrow_gather_launch(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g, int act, hipStream_t s);
+bool tapn_gather_applicable(const ConvGeom& g, int act);
+int tapn_gather_launch(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g, int act, hipStream_t s);
 int narrow_wgrad_kind(const ConvGeom& g);
 size_t narrow_wgrad_ws_floats(const ConvGeom& g);
 int narrow_wgrad_launch(const float* big, const float* small, float* dw_ref, const ConvGeom& g, float* ws, hipStream_t s);

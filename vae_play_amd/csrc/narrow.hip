@@ -472,18 +472,21 @@ bool narrow_gather_applicable(const ConvGeom& g, int act) {
   return g.ks == 5 && g.Hb == g.Hs && g.Wb == g.Ws && g.stride == 1 && (g.Cs == 1 || g.Cs == 3) && g.Cb % 16 == 0 && (act == ACT_NONE || act == ACT_SIGMOID);
 }
 
+// split-bf16 arithmetic on the matrix cores (conv5s1_tapn_kernel): 64 input channels, 1 or 3 outputs
+bool tapn_gather_applicable(const ConvGeom& g, int act) {
+  return narrow_gather_applicable(g, act) && g.Cb == 64;
+}
+int tapn_gather_launch(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g, int act, hipStream_t s) {
+  const int tiles_x = (g.Ws + 15) / 16, tiles_per_img = tiles_x * ((g.Hs + 15) / 16), ntiles = tiles_per_img * g.B;
+  const dim3 pgrid((unsigned)(ntiles < 256 ? ntiles : 256));          // one persistent workgroup per CU
+  if (g.Cs == 3) hipLaunchKernelGGL((conv5s1_tapn_kernel<3>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act);
+  else hipLaunchKernelGGL((conv5s1_tapn_kernel<1>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act);
+  return check_launch("conv5s1_tapn");
+}
+
 int narrow_gather_launch(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g, int act,
                          hipStream_t s) {
   dim3 grid((g.Ws + 15) / 16, (g.Hs + 15) / 16, g.B);
-  // 64 input channels (every decoder of models/networks.py ends in 64): the matrix-core kernel; VP_TAPN=0 keeps the VALU kernel
-  static const bool tapn = [] { const char* e = getenv("VP_TAPN"); return !e || atoi(e) != 0; }();
-  if (tapn && g.Cb == 64 && ((uintptr_t)big & 15) == 0 && ((uintptr_t)w_p0 & 15) == 0) {
-    const int tiles_x = (g.Ws + 15) / 16, tiles_per_img = tiles_x * ((g.Hs + 15) / 16), ntiles = tiles_per_img * g.B;
-    const dim3 pgrid((unsigned)(ntiles < 256 ? ntiles : 256));          // one persistent workgroup per CU
-    if (g.Cs == 3) hipLaunchKernelGGL((conv5s1_tapn_kernel<3>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act);
-    else hipLaunchKernelGGL((conv5s1_tapn_kernel<1>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act);
-    return check_launch("conv5s1_tapn");
-  }
   if (g.Cs == 3)
     hipLaunchKernelGGL((conv5s1_smallout_kernel<3>), grid, dim3(256), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, g.Cb, act);
   else

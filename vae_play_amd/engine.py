@@ -340,6 +340,10 @@ class FusedVAEStep:
             pack(fin.weight, fp0s, None, C, Cf, True)
             fwd.add("vp_conv5_gather_bf16x3", P(dec_in_s[-1]), P(fp0s), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, 1, _ACT_SIGMOID,
                     flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
+        elif x3 and Cf == 64 and C in (1, 3) and os.environ.get("VP_TAPN", "1") != "0":
+            # split-bf16 on the matrix cores, taps folded into the MFMA columns (the exact-f32 plan keeps the VALU kernel)
+            fwd.add("vp_conv5_smallout_bf16x3", P(dec_in[-1]), P(fp0), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, _ACT_SIGMOID,
+                    flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
         else:
             fwd.add("vp_conv5_gather_f32", P(dec_in[-1]), P(fp0), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, 1, _ACT_SIGMOID,
                     flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
