@@ -107,6 +107,64 @@ def test_optimizer_state_round_trip_on_device(tmp_path):
         assert torch.equal(p, q)
 
 
+@pytest.mark.gpu
+def test_optimizer_state_round_trip_with_foreign_parameters(tmp_path):
+    """Two optimisers over overlapping parameters (train_BE_font.py:280-282: Adam over the whole generator and a second Adam
+    over its style encoder): the second one owns no arena slice at all, its moments and per-tensor step counts are "foreign"
+    state and must survive a checkpoint, as the reference's pickled optimisers do (train.py:157)."""
+    import vae_play_amd as V
+    from vae_play_amd import checkpoint, optim
+
+    def build(seed):
+        torch.manual_seed(seed)
+        net = V.DirectDecoder(16).cuda()
+        sub = [p for n, p in net.named_parameters() if n.startswith("r_fc")]
+        return net, optim.Adam(net.parameters(), lr=1e-3), optim.Adam(sub, lr=2e-3, betas=(0.8, 0.95)), optim.RMSprop(sub, lr=1e-3, alpha=0.9)
+
+    net, oa, ob, oc = build(1)
+    assert ob.arena.numel == 0 and len(ob.arena.foreign) > 0
+    for i in range(3):
+        for o in (oa, ob, oc):
+            o.zero_grad()
+        net(torch.randn(4, 16, device="cuda")).sum().backward()
+        (oa, ob, oc)[i % 3].step()
+        ob.step()
+    path = str(tmp_path / "f.ckpt")
+    checkpoint.save_checkpoint(path, {"AUX": net}, {"a": oa, "b": ob, "c": oc}, epoch=2)
+    net2, oa2, ob2, oc2 = build(5)
+    checkpoint.load_checkpoint(path, {"AUX": net2}, {"a": oa2, "b": ob2, "c": oc2})
+    assert ob2.betas == (0.8, 0.95) and oc2.alpha == 0.9
+    for (_, m, v, c), (_, m2, v2, c2) in zip(ob._fstate, ob2._fstate):
+        assert torch.equal(m, m2) and torch.equal(v, v2) and c == c2 and c[0] == 4
+    x = torch.randn(4, 16, device="cuda")
+    for n, a, b, c in ((net, oa, ob, oc), (net2, oa2, ob2, oc2)):
+        for o in (a, b, c):
+            o.zero_grad()
+        n(x).sum().backward()
+        b.step(); c.step(); a.step()
+    for p, q in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(p, q)
+    bad = oa.state_dict()
+    with pytest.raises(ValueError):
+        ob2.load_state_dict(bad)          # kind matches, arena size and foreign entries do not
+
+
+@pytest.mark.gpu
+def test_fused_step_counters_reach_the_checkpoint(tmp_path):
+    """FusedVAEStep advances BatchNorm num_batches_tracked lazily; state_dict() (hence save_checkpoint) must see the true value."""
+    import vae_play_amd as V
+    from vae_play_amd import engine, optim
+    vae = V.VAE(32, 16, 1).cuda().train()
+    opt = optim.Adam(vae.parameters(), lr=1e-4)
+    fused = engine.FusedVAEStep(vae, opt, 4, 32, 1)
+    x, eps = torch.rand(4, 1, 32, 32, device="cuda"), torch.randn(4, 16, device="cuda")
+    for _ in range(3):
+        fused.step(x, eps)
+    assert int(vae.state_dict()["encoder.conv.0.bn.num_batches_tracked"]) == 3
+    bn = vae.encoder.conv[0].bn
+    assert fused._bn_momentum_eps[id(bn)] == (bn.momentum, bn.eps)
+
+
 def test_every_script_compiles():
     """tools/, tests/diag/, examples/, profiles/*.py and the two root entry points are scripts that only run on a GPU box:
     keep at least their syntax under the CPU suite."""

@@ -121,6 +121,16 @@ class FusedVAEStep:
         self._bufs: Dict[str, torch.Tensor] = {}
         self._graph = None
         self._build()
+        # BatchNorm ``num_batches_tracked`` is advanced lazily (sync_counters): make every state_dict() / checkpoint of the model
+        # see the true counters
+        import weakref
+        me = weakref.ref(self)
+
+        def _sync(module, prefix, keep_vars):
+            o = me()
+            if o is not None:
+                o.sync_counters()
+        self._sd_hook = vae.register_state_dict_pre_hook(_sync)
 
     # ---- buffers ----------------------------------------------------------------------------
     def _buf(self, name: str, *shape) -> torch.Tensor:
@@ -143,6 +153,7 @@ class FusedVAEStep:
         B, S, C, Z, L = self.B, self.S, self.C, self.Z, self.L
         enc, dec = self.vae.encoder, self.vae.decoder
         fwd, bwd = _Plan(), _Plan()
+        self._bn_momentum_eps = {}
         P = _ptr
         pack_jobs = []   # every conv weight is re-packed by ONE launch at the head of the forward plan
         # Weight gradients go to a side stream (bf16x3 plans): they only feed the optimiser, so they can run underneath
@@ -186,6 +197,7 @@ class FusedVAEStep:
             mean, rstd = self._buf(f"{tag}.mean", Cn), self._buf(f"{tag}.rstd", Cn)
             ws = self._ws(f"{tag}.bnws", lib.vp_bn_workspace_bytes(R, Cn))
             mom, eps_bn = float(bn_mod.momentum), float(bn_mod.eps)
+            self._bn_momentum_eps[id(bn_mod)] = (mom, eps_bn)
             fused = False
             if conv is not None:
                 family, name, lead, geom, fl, ctag = conv

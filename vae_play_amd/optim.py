@@ -90,8 +90,23 @@ class _FlatOptimizer:
     # ---- checkpointing: plain tensors / numbers only (vae_play_amd/checkpoint.py) -------------------------
     _STATE = ()
 
+    def _hyper(self) -> dict:
+        return {}
+
+    def _foreign_state(self) -> list:
+        """Per-tensor state of the parameters that live in another optimiser's arena, in parameter order."""
+        return []
+
+    def _load_foreign_state(self, items: list) -> None:
+        if items:
+            raise ValueError("optimizer state carries foreign-parameter entries this optimizer does not have")
+
     def state_dict(self) -> dict:
-        out = {"kind": type(self).__name__, "lr": float(self.lr), "step_count": int(self.step_count), "numel": int(self.arena.numel)}
+        """Arena moments, hyper-parameters and the per-tensor state of foreign parameters (those owned by another optimiser's
+        arena: the font GAN's style-encoder Adam, train_BE_font.py:280-281, has nothing but such parameters) -- the reference
+        pickles the whole optimiser (train.py:157); here everything is plain tensors and numbers."""
+        out = {"kind": type(self).__name__, "lr": float(self.lr), "step_count": int(self.step_count), "numel": int(self.arena.numel),
+               "hyper": self._hyper(), "foreign": self._foreign_state()}
         for k in self._STATE:
             out[k] = getattr(self, k).detach().cpu()
         return out
@@ -99,9 +114,19 @@ class _FlatOptimizer:
     def load_state_dict(self, sd: dict) -> None:
         if sd.get("kind") != type(self).__name__ or int(sd.get("numel", -1)) != self.arena.numel:
             raise ValueError("optimizer state does not match this optimizer (kind / parameter arena size)")
+        foreign = sd.get("foreign", [])
+        if len(foreign) != len(self.arena.foreign):
+            raise ValueError(f"optimizer state has {len(foreign)} foreign-parameter entries, this optimizer has {len(self.arena.foreign)}")
+        for item, p in zip(foreign, self.arena.foreign):
+            for t in item["tensors"]:
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError("foreign-parameter state does not match the parameter's shape")
         self.lr, self.step_count = float(sd["lr"]), int(sd["step_count"])
+        for k, v in sd.get("hyper", {}).items():
+            setattr(self, k, tuple(v) if isinstance(v, (list, tuple)) else v)
         for k in self._STATE:
             getattr(self, k).copy_(sd[k])
+        self._load_foreign_state(foreign)
 
     @property
     def flat_grad(self) -> torch.Tensor:
@@ -123,6 +148,16 @@ class Adam(_FlatOptimizer):
         self._STATE = ("exp_avg", "exp_avg_sq")
         # parameters owned by another arena: per-tensor state and step count (torch skips a tensor without a gradient)
         self._fstate = [(p, torch.zeros_like(p.data), torch.zeros_like(p.data), [0]) for p in self.arena.foreign]
+
+    def _hyper(self) -> dict:
+        return {"betas": [float(self.betas[0]), float(self.betas[1])], "eps": float(self.eps)}
+
+    def _foreign_state(self) -> list:
+        return [{"tensors": [m.detach().cpu(), v.detach().cpu()], "count": int(cnt[0])} for _, m, v, cnt in self._fstate]
+
+    def _load_foreign_state(self, items: list) -> None:
+        for (_, m, v, cnt), item in zip(self._fstate, items):
+            m.copy_(item["tensors"][0]); v.copy_(item["tensors"][1]); cnt[0] = int(item["count"])
 
     # ---- sliced update (engine.FusedVAEStep.step): begin_step() once, then step_range() per arena slice ---------
     def begin_step(self) -> None:
@@ -162,6 +197,16 @@ class RMSprop(_FlatOptimizer):
         self.square_avg = torch.zeros_like(self.arena.flat_param)
         self._STATE = ("square_avg",)
         self._fstate = [(p, torch.zeros_like(p.data)) for p in self.arena.foreign]
+
+    def _hyper(self) -> dict:
+        return {"alpha": float(self.alpha), "eps": float(self.eps)}
+
+    def _foreign_state(self) -> list:
+        return [{"tensors": [sq.detach().cpu()], "count": 0} for _, sq in self._fstate]
+
+    def _load_foreign_state(self, items: list) -> None:
+        for (_, sq), item in zip(self._fstate, items):
+            sq.copy_(item["tensors"][0])
 
     def begin_step(self) -> None:
         self.step_count += 1
