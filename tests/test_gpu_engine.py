@@ -207,3 +207,37 @@ def test_fused_step_binds_or_copies_the_callers_batch():
     assert l2.item() != loss0
     l3, _, _ = fused.forward_backward(xd, epsd)
     assert l3.item() == loss0
+
+
+def test_graph_replay_of_the_concurrent_bf16x3_plan_is_bit_identical():
+    """FusedVAEStep.capture() on the split-bf16 plan records the side-stream forks / joins (weight gradients and the weight
+    re-pack run on a second stream, the split output gradient ping-pongs between two buffers): the replayed graph must write
+    exactly the gradients of the eager launch, and capturing must leave the BatchNorm buffers untouched."""
+    from oracle import ref_cpu as O
+    C, S, z, B = 3, 64, 32, 8
+    vae, opt, fused, p0, L = build(C, S, z, B, precision="bf16x3")
+    assert fused._n_side_events > 0
+    x, eps = O.synthetic_batch(B, C, S, z)
+    xd, epsd = x.to(DEV), eps.to(DEV)
+    sd0 = {k: v.clone() for k, v in vae.state_dict().items()}
+    used = torch.zeros_like(opt.flat_grad, dtype=torch.bool)
+    for p, o in zip(opt.arena.params, opt.arena.offsets):
+        used[o:o + p.numel()] = True
+    opt.flat_grad.fill_(float("nan"))
+    loss_e = fused.forward_backward(xd, epsd)[0].item()
+    torch.cuda.synchronize()
+    g_eager = opt.flat_grad.clone()
+    rm_eager = vae.decoder.conv[0].bn.running_mean.clone()
+    assert torch.isfinite(g_eager[used]).all()
+    vae.load_state_dict(sd0)
+    fused.capture()
+    for k in ("decoder.conv.0.bn.running_mean", "encoder.conv.1.bn.running_var", "encoder.fc.1.running_mean"):
+        assert torch.equal(vae.state_dict()[k], sd0[k]), f"capture() changed {k}"
+    for rep in range(2):
+        vae.load_state_dict(sd0)
+        opt.flat_grad.fill_(float("nan"))
+        loss_g = fused.forward_backward(xd, epsd)[0].item()
+        torch.cuda.synchronize()
+        assert torch.equal(opt.flat_grad[used], g_eager[used]), f"graph replay {rep} differs from the eager launch"
+        assert loss_g == loss_e
+        assert torch.equal(vae.decoder.conv[0].bn.running_mean, rm_eager)

@@ -1,6 +1,7 @@
 // Split-bf16 ("bf16x3") convolution families: C ABI + the producers of split planes.
+#include <type_traits>
 #include "common.h"
-#include "igemm16.h"
+#include "igemm16p.h"
 #include "halo.h"
 #include "narrow.h"
 #include "split.h"
@@ -226,6 +227,35 @@ static long conv_split_tiles() {
   return e ? atol(e) : 384;
 }
 
+// Kernel choice for a plain 5x5 VAE layer on split planes: the pipelined LDS-DMA kernel (igemm16p.h, bit-identical results) takes
+// the shapes where its 256x256 eight-wave tile fills the chip -- N a multiple of 256 and at least one workgroup per CU, i.e. the
+// N >= 256 layers from ~128 images per GPU on (+5-10 % there, profiles/r02_notes.md); everything else stays on igemm16_kernel.
+// VP_IGEMM16P=0 disables it, VP_IGEMM16P_CFG=<n> forces configuration n of igemm16p.h wherever it applies (experiments).
+struct Launch16 { int pcfg, bm, bn; };
+static Launch16 plan16(long M, long N, int gz, int ctile, int nsplit, size_t plane_elems_a, size_t plane_elems_b, long kmin) {
+  const Tile16 t = choose_tile16(M, N, gz);
+  Launch16 l = {PCFG_NONE, t.bm, t.bn};
+  static const int mode = [] { const char* e = getenv("VP_IGEMM16P"); return e ? atoi(e) : 1; }();
+  static const int forced = [] { const char* e = getenv("VP_IGEMM16P_CFG"); return e ? atoi(e) : 0; }();
+  if (!mode || nsplit != 1 || ctile % 32 != 0 || kmin / 32 < 4) return l;
+  if (plane_elems_a >= ((size_t)1 << 29) || plane_elems_b >= ((size_t)1 << 29)) return l;      // 32-bit byte offsets of both planes
+  int cfg = PCFG_NONE;
+  if (forced > PCFG_NONE && forced < PCFG_COUNT) cfg = forced;
+  else if (N % 256 == 0 && M >= 256 && ((M + 255) / 256) * (N / 256) * gz >= 256) cfg = PCFG_256x256_S2;
+  if (cfg == PCFG_NONE) return l;
+  int bm, bn;
+  pcfg_tile(cfg, bm, bn);
+  if (bn > N || bm > M) return l;
+  l.pcfg = cfg; l.bm = bm; l.bn = bn;
+  return l;
+}
+static int xcd_map_tile(long M, long N, int bm, int bn) {
+  const char* e = getenv("VP_XCD_MAP");
+  if (e && atoi(e) == 0) return 0;
+  const long gx = (M + bm - 1) / bm, gy = (N + bn - 1) / bn;
+  return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
+}
+
 // split-K decisions (shared by the launchers and by the statistics plan)
 static int gather_nsplit(long M, int N, int K, int Cbig, bool plain5, bool has_bias, int act) {
   // few output tiles and a long K (the 8x8-resolution layers: 256 workgroups = one per CU): split K in two and
@@ -254,6 +284,16 @@ static int gather16_t(const void* big_split, const void* w_p0_split, const float
   p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
   if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
+  if constexpr (std::is_same<PF, ProbF16>::value) {
+    const Launch16 l = plan16(p.M, p.N, p.nsplit, Cbig, p.nsplit, p.big_plane, p.w_plane, p.k_per_split);
+    if (l.pcfg != PCFG_NONE) {
+      PF16 q;
+      static_cast<ProbF16&>(q) = p;
+      q.xcd_map = xcd_map_tile(p.M, p.N, l.bm, l.bn);
+      launch_igemm16p(q, l.pcfg, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig, true, false);
+      return check_launch("vp_conv_gather_bf16x3(pipelined)");
+    }
+  }
   p.xcd_map = xcd_map_for(p.M, p.N, p.nsplit);
   launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig);
   return check_launch("vp_conv_gather_bf16x3");
@@ -274,6 +314,16 @@ static int scatter16_t(const void* small_split, const void* w_p1_split, float* b
   if (p.nsplit == 2 &&
       hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
+  if constexpr (std::is_same<PT, ProbT16>::value) {
+    const Launch16 l = plan16(p.M, p.N, stride * stride * p.nsplit, Csmall, p.nsplit, p.small_plane, p.w_plane, (long)stride * stride * Csmall);
+    if (l.pcfg != PCFG_NONE && stride == 2) {
+      PT16 q;
+      static_cast<ProbT16&>(q) = p;
+      q.xcd_map = xcd_map_tile(p.M, p.N, l.bm, l.bn);
+      launch_igemm16p(q, l.pcfg, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall, true, false);
+      return check_launch("vp_conv_scatter_bf16x3(pipelined)");
+    }
+  }
   p.xcd_map = xcd_map_for(p.M, p.N, stride * stride * p.nsplit);
   launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
   return check_launch("vp_conv_scatter_bf16x3");
@@ -473,9 +523,11 @@ StatPlan stat_plan(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int 
     sp.gz = stride * stride;
     sp.R = sp.M * stride * stride;
   }
-  const Tile16 t = choose_tile16(sp.M, sp.N, sp.gz);
-  sp.bm = t.bm;
-  sp.tiles_m = (int)((sp.M + t.bm - 1) / t.bm);
+  const size_t act_plane = family == 0 ? (size_t)sp.M * stride * stride * Cbig : (size_t)sp.M * Csmall;
+  const Launch16 l = family == 0 ? plan16(sp.M, sp.N, sp.gz, Cbig, 1, act_plane, (size_t)Csmall * Cbig * 25, 25L * Cbig)
+                                 : plan16(sp.M, sp.N, sp.gz, Csmall, 1, act_plane, (size_t)Csmall * Cbig * 25, (long)stride * stride * Csmall);
+  sp.bm = (l.pcfg != PCFG_NONE && !(family == 1 && stride != 2)) ? l.bm : choose_tile16(sp.M, sp.N, sp.gz).bm;
+  sp.tiles_m = (int)((sp.M + sp.bm - 1) / sp.bm);
   sp.ok = 1;
   return sp;
 }

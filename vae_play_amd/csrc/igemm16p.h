@@ -311,6 +311,11 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) igemm16p_kernel(const P p)
     }
   }
 
+  if (p.stat) {      // BatchNorm statistics of the tile (igemm16.h epilogue_stats32); the ring is idle: every DMA has landed
+    __syncthreads();
+    epilogue_stats32<BM, BN, WM, WN, TM, TN>(p.stat, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, p.M, p.N, acc, lds, m0, n0,
+                                             wm, wn, li, lh, tid);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
