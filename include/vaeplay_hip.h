@@ -109,6 +109,13 @@ int vp_conv5_scatter_bf16x3(const void* small_split, const void* w_p1_split, flo
  * input (split into bf16 hi/lo in registers) and the fp32 packed weights P0 [C][25][64] of vp_pack_w5_f32, fp32 output. */
 int vp_conv5_smallout_bf16x3(const float* big, const float* w_p0, const float* bias, float* small_out, int B, int H, int W,
                              int Cbig, int Csmall, int act, vp_stream stream);
+/* ... and its weight gradient dW[C][64][5][5] = sum_pixels dlogit x shifted activation, with the 25 taps x C gradient channels as
+ * the MFMA row dimension ("taps in M", csrc/edge.hip): fp32 activation [B,H,W,64] and fp32 dlogit [B,H,W,C] in, reference weight
+ * layout out; deterministic slab reduction.  The workspace query returns 0 for shapes it does not take (width not a multiple of
+ * 64, height not of 16): use vp_conv5_wgrad_f32 there. */
+size_t vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(int B, int H, int W, int Cbig, int Csmall);
+int vp_conv5_smallout_wgrad_bf16x3(const float* big, const float* small, float* dw_ref, int B, int H, int W, int Cbig, int Csmall,
+                                   void* ws, size_t ws_bytes, vp_stream stream);
 /* First encoder conv (nn.Conv2d(C, 64, k5, s2, p2, bias=False) with C = 1 or 3 image channels, models/networks.py:14 via :55):
  * its im2col is materialised once per step as split planes [B*Hs*Ws][KC] (KC = vp_im2col5s2_cols(C): 96 / 64), after which the
  * forward convolution is vp_conv_gather_bf16x3(ks = 1, Cbig = KC) and the weight gradient vp_conv_wgrad_bf16x3(ks = 1) on the

@@ -1,0 +1,6 @@
+"""Alias: ``models.networks`` -> ``vae_play_amd.networks`` (same class names, constructor signatures and state_dict keys as the
+reference module of this name; every op underneath is a HIP kernel behind the C ABI)."""
+from vae_play_amd.networks import *  # noqa: F401,F403
+from vae_play_amd import networks as _impl
+
+__all__ = [n for n in dir(_impl) if not n.startswith("_")]

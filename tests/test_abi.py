@@ -101,3 +101,15 @@ def test_oracle_matches_golden_step():
     for k in ("mu", "logvar", "z", "x_tilde"):
         assert torch.allclose(out[k], t(g[k]), rtol=1e-5, atol=1e-6), k
     assert abs(out["loss"].item() - g["loss"][0]) <= 1e-5 * abs(g["loss"][0])
+
+
+def test_reference_module_paths_resolve_to_the_drop_in_classes():
+    """``models.networks`` / ``models.blocks`` / ``models.networks_BE*`` (the reference's import paths, which its scripts and its
+    pickled checkpoints name: train.py:9, test_BE.py:79-80) are aliases of the HIP-backed implementations."""
+    import importlib
+    import vae_play_amd
+    for name, probe in (("networks", "Encoder"), ("networks", "VaeGan"), ("blocks", "Conv2d"), ("networks_BE", "ComposeNet"),
+                        ("networks_BE_GAN", "Discriminator"), ("networks_BE_font", "ComposeNet")):
+        alias = importlib.import_module(f"models.{name}")
+        impl = importlib.import_module(f"vae_play_amd.{name}")
+        assert getattr(alias, probe) is getattr(impl, probe), f"models.{name}.{probe}"

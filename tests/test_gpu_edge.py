@@ -35,3 +35,28 @@ def test_final_conv_tapn_matches_torch(B, H, W, nout, act):
     # image borders are where the halo patch is zero-filled: check them on their own
     for sl in ((..., 0, slice(None)), (..., H - 1, slice(None)), (..., slice(None), 0), (..., slice(None), W - 1)):
         assert_close(y.cpu()[sl], ref[sl], 1e-4, "border")
+
+
+@pytest.mark.parametrize("B,H,W,nout", [(2, 16, 64, 3), (1, 32, 128, 1), (3, 48, 64, 3), (2, 128, 128, 3), (1, 256, 256, 1)])
+def test_final_conv_weight_gradient_tapm_matches_torch(B, H, W, nout):
+    """csrc/edge.hip wgrad_tapm_kernel (taps folded into the MFMA rows) against torch's autograd weight gradient on the CPU and
+    against the exact-fp32 VALU kernel behind vp_conv5_wgrad_f32."""
+    from vae_play_amd import _lib, ops
+    g = torch.Generator().manual_seed(11 + H + nout)
+    u = torch.rand(B, 64, H, W, generator=g) * 1.5                      # post-ReLU activation
+    dl = (torch.rand(B, nout, H, W, generator=g) - 0.5) / B             # (x_tilde - x) / B
+    w = torch.zeros(nout, 64, 5, 5, requires_grad=True)
+    (F.conv2d(u, w, None, padding=2) * dl).sum().backward()
+    ref = w.grad
+    ud, dld = ops.channels_last(u.cuda()), ops.channels_last(dl.cuda())
+    lib = _lib.load()
+    nbytes = lib.vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(B, H, W, 64, nout)
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4, device="cuda")
+    dw = torch.full((nout, 64, 5, 5), float("nan"), device="cuda")
+    _lib.call("vp_conv5_smallout_wgrad_bf16x3", ops._p(ud), ops._p(dld), ops._p(dw), B, H, W, 64, nout, ops._p(ws), nbytes, ops._stream())
+    assert_close(dw.cpu(), ref, 3e-5, f"final conv wgrad taps-in-M {B}x{H}x{W}x{nout}")
+    assert_close(dw.cpu(), ops.conv5_wgrad(ud, dld, 1).cpu(), 3e-5, "taps-in-M vs exact-f32 kernel")
+    dw2 = torch.empty_like(dw)
+    _lib.call("vp_conv5_smallout_wgrad_bf16x3", ops._p(ud), ops._p(dld), ops._p(dw2), B, H, W, 64, nout, ops._p(ws), nbytes, ops._stream())
+    assert torch.equal(dw, dw2), "slab reduction must be bit-reproducible"

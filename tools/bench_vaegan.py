@@ -42,6 +42,40 @@ def step(net, opts, x, targets, eps, z_p, V, lam, fused=True, dp=None):
     return loss_encoder
 
 
+def step_gflop_per_image(img: int, z: int) -> float:
+    """Algorithmic GFLOP of one VAE-GAN training step per image (2 x MACs; transposed convolutions without zero insertion;
+    backward = 2 x forward; the discriminator sees three images per input image; dense layers included)."""
+    import math
+    L = int(math.log2(img // 8))
+    mac = 0.0
+    ch, s = 1, img                                  # encoder (1 image channel)
+    for i in range(L):
+        co = 64 if i == 0 else ch * 2
+        s //= 2
+        mac += s * s * 25 * ch * co
+        ch = co
+    size = ch
+    mac += 64 * size * 1024 + 2 * 1024 * z
+    dec = z * 64 * size                             # decoder, run twice (x_tilde and x_p)
+    c, s = size, 8
+    for i in range(L):
+        co = size if i == 0 else c // 2
+        dec += s * s * 25 * c * co
+        c, s = co, s * 2
+    dec += s * s * 25 * c * 1
+    mac += 2 * dec
+    d = img * img * 25 * 1 * 32                     # discriminator on (x, x_tilde, x_p)
+    c, s = 32, img
+    for i in range(L):
+        s //= 2
+        d += s * s * 25 * c * (2 * c)
+        c *= 2
+    d += 64 * c * 512 + 512
+    mac += 3 * d
+    mac += z * 512 + 512 * 256 + 256 * 128 + 128 * 64 + 2 * 64 * 32 + 32 * 3     # param_encoder
+    return 3 * 2 * mac * 1e-9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--img", type=int, default=128)
@@ -93,6 +127,14 @@ def main():
                                                          "path": f"autograd modules on HIP kernels ({a.precision} convolutions)",
                                                          "backward": "five passes (train.py:69-73)" if a.five_pass else "one pass over the summed losses"},
            "loss_encoder": float(loss.detach())}
+    gf = step_gflop_per_image(a.img, a.z)
+    ach = world * a.batch / dt * gf / 1e3 / world          # algorithmic TFLOP/s per GPU over the whole step
+    peak = 2500.0 if a.precision == "bf16x3" else 157.3
+    out["dtype"] = a.precision
+    out["roofline"] = {"bound": "mfma", "kernel": "whole step (autograd front end; per-kernel table: profiles/*_vaegan_summary.md)",
+                       "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                       "mfma_issue_frac": round(ach * (3 if a.precision == "bf16x3" else 1) / peak, 4), "traffic": None,
+                       "step_gflop_per_image": round(gf, 3)}
     if world > 1:
         if rank == 0:
             print(json.dumps(out))
@@ -102,7 +144,14 @@ def main():
     if a.cpu_steps > 0:
         from oracle import ref_cpu as O
         from oracle import ref_vaegan as G
-        torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+        quota = None
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                q, per = f.read().split()[:2]
+                quota = None if q == "max" else max(1, int(float(q) / float(per) + 0.5))
+        except (OSError, ValueError):
+            pass
+        torch.set_num_threads(min(len(os.sched_getaffinity(0)), quota or 1 << 30))
         p = G.init_vaegan_params(a.img, a.z, seed=0)
         O.require_grad(p)
         o_opts = G.make_optimizers(p)
