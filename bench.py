@@ -36,8 +36,11 @@ STEP_GFLOP = {32: 0.6141, 64: 4.0301, 128: 22.2088, 256: 112.0225}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32", "vp_conv5_gather_stats_bf16x3", "vp_conv5_scatter_stats_bf16x3",
-              "vp_conv5_gather_bf16x3", "vp_conv5_scatter_bf16x3", "vp_conv5_wgrad_bf16x3",
-              "vp_conv_gather_bf16x3", "vp_conv_wgrad_bf16x3"}
+              "vp_conv5_gather_bf16x3", "vp_conv5_scatter_bf16x3", "vp_conv5_wgrad_bf16x3", "vp_conv5_gather_bnbwd_bf16x3",
+              "vp_conv5_scatter_bnbwd_bf16x3",
+              "vp_conv_gather_bf16x3", "vp_conv_wgrad_bf16x3",
+              "vp_conv5_gather_f16", "vp_conv5_scatter_f16", "vp_conv5_wgrad_f16x2", "vp_conv5_gather_stats_f16",
+              "vp_conv5_scatter_stats_f16", "vp_conv_gather_f16", "vp_conv_wgrad_f16x2"}
 
 
 def measured_traffic(api_name):
@@ -63,7 +66,7 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph "
                     "(roofline events are then taken in a separate instrumented pass)")
-    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
+    ap.add_argument("--precision", choices=["bf16x3", "f32", "f16x2"], default="bf16x3",
                     help="bf16x3: split-bf16 MFMA (3 bf16 MFMAs per product, fp32 accumulate, ~1e-5 parity); "
                          "f32: exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -214,7 +217,7 @@ def measure(fused, x, eps, steps, untimed, world, graph, overlap=True, tags_out=
         measured = "instrumented-pass-after-timed-region"
     fam = {}
     for name, tag, flops, e0, e1 in timers["events"]:
-        d = fam.setdefault(name.replace("_stats_bf16x3", "_bf16x3"), [0.0, 0.0, 0])
+        d = fam.setdefault(name.replace("_stats_", "_").replace("_bnbwd_", "_"), [0.0, 0.0, 0])
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
@@ -236,9 +239,12 @@ def roofline_of(m, steps, B, S, C, z):
     tot_f = sum(v[0] for v in fam.values())
     tot_t = sum(v[1] for v in fam.values())
     ach = fam[dom][0] / fam[dom][1] / 1e12
-    is16 = dom.endswith("bf16x3")
-    peak = PEAK_BF16_MFMA_TFLOPS if is16 else PEAK_FP32_MFMA_TFLOPS
-    kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if is16
+    is16 = dom.endswith("bf16x3") or dom.endswith("f16x2") or dom.endswith("_f16")
+    # the fp16 gather / scatter entry points carry forward (3 products) and backward (2 products) launches: priced at 2
+    per_product = 3 if dom.endswith("bf16x3") else (2 if is16 else 1)
+    peak = PEAK_BF16_MFMA_TFLOPS if is16 else PEAK_FP32_MFMA_TFLOPS       # fp16 and bf16 MFMAs have the same dense peak
+    kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if per_product == 3
+             else "igemm16_kernel, 2 (backward) or 3 (forward) x v_mfma_f32_32x32x16_f16 per product" if per_product == 2
              else "igemm_kernel, v_mfma_f32_32x32x2_f32")
     # the committed PMC passes were taken on the default workload only
     traffic, traffic_src = measured_traffic(dom) if (S, C, z, B) == (128, 3, 128, 32) else (None, None)
@@ -246,7 +252,7 @@ def roofline_of(m, steps, B, S, C, z):
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
             "traffic_source": traffic_src,
-            "mfma_issue_frac": round(ach * (3 if is16 else 1) / peak, 4),
+            "mfma_issue_frac": round(ach * per_product / peak, 4),
             "launches": fam[dom][2], "avg_launch_ms": round(fam[dom][1] / fam[dom][2] * 1e3, 4),
             "all_conv_families_tflops": round(tot_f / tot_t / 1e12, 2),
             "conv_share_of_step_time": round(tot_t / m["n_inst"] / (m["elapsed"] / steps), 3),
@@ -318,7 +324,7 @@ def main():
             "metric": f"images/sec (train step, {S}x{S} VAE)", "value": round(ips, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": n_settle,
             "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"networks VAE {S}x{S}x{C} latent={z} train step (fwd+BCE/KL+bwd+allreduce+Adam), "
                                    f"{B} images/GPU, global batch {B * world}", "parallelism": f"dp{world}",
                        "per_gpu_batch": B, "global_batch": B * world, "graph": bool(args.graph),
@@ -336,6 +342,8 @@ def main():
         todo = []
         if args.precision != "f32":
             todo.append(("f32", B, S, C, z))
+        if args.precision != "f16x2":      # the cheaper contraction mode (declared tolerance 1e-3 on outputs, tests/test_gpu_f16x2.py)
+            todo.append(("f16x2", B, S, C, z))
         for b2 in (64, 128, 256):
             if b2 != B:
                 todo.append((args.precision, b2, S, C, z))

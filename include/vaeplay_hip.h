@@ -140,6 +140,23 @@ int vp_conv5_scatter_stats_bf16x3(const void* small_split, const void* w_p1_spli
                                   int B, int Hs, int Ws, int Csmall, int Cbig, int stride, float eps, float momentum,
                                   float* mean, float* rstd, float* running_mean, float* running_var,
                                   void* ws, size_t ws_bytes, vp_stream stream);
+/* Input-gradient convolution + the reduction pass of the BatchNorm backward it feeds (autograd of nn.BatchNorm2d + F.relu,
+ * models/networks.py:28-29,44-45): the launch's output small_out / big_out is dy of a BatchNorm(+ReLU) layer whose convolution
+ * output is bn_x (same layout); the epilogue emits per-workgroup {sum g, sum g*xhat}, g = dy * act'(gamma*xhat + beta), and one
+ * finaliser writes sums[0..C) = sum g, sums[C..2C) = sum g*xhat and the affine gradients (dbeta = sum g, dgamma = sum g*xhat;
+ * either may be NULL).  vp_bn_act_bwd_apply_split_f32 then produces dx from them: together they replace vp_bn_act_bwd_split_f32
+ * without its separate read of dy and x for the sums.  Shapes: as vp_conv5_*_stats_bf16x3 (same workspace query). */
+int vp_conv5_gather_bnbwd_bf16x3(const void* big_split, const void* w_p0_split, float* small_out,
+                                 int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
+                                 const float* bn_x, const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
+                                 int act, float* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_conv5_scatter_bnbwd_bf16x3(const void* small_split, const void* w_p1_split, float* big_out,
+                                  int B, int Hs, int Ws, int Csmall, int Cbig, int stride,
+                                  const float* bn_x, const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
+                                  int act, float* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_bn_act_bwd_apply_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, const float* sums, float* dx, void* dx_split, int R, int C, int act, float slope,
+                                  int batch_stats, vp_stream stream);
 size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride);
 int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref,
                           int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
@@ -154,7 +171,7 @@ int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, 
                             void* ws, size_t ws_bytes, vp_stream stream);
 int vp_nchw_to_nhwc_split_f32(const float* in, float* out, void* out_split, int B, int C, int H, int W, vp_stream stream);
 /* Every conv weight of a step in ONE launch: job i packs w (reference layout [Csmall][Cbig][5][5]) into p0
- * ([Csmall][25][Cbig]) and/or p1 ([Cbig][25][Csmall_pad]); split != 0 writes bf16 hi/lo planes, else fp32.
+ * ([Csmall][25][Cbig]) and/or p1 ([Cbig][25][Csmall_pad]); split = 1 writes bf16 hi/lo planes, 2 fp16 hi/lo planes, 0 fp32.
  * jobs is a HOST array (read during the call only); at most 32 output layouts per batch. */
 typedef struct vp_pack_job {
   const float* w;
@@ -285,6 +302,56 @@ int vp_vae_loss_f32(const float* x_tilde, const float* x, size_t n, const float*
                     float* loss, float loss_scale, void* ws, size_t ws_bytes, vp_stream stream);
 /* out = a + b (the two latent heads' input gradients, models/networks.py:76-77 backward) */
 int vp_add_f32(const float* a, const float* b, float* out, size_t n, vp_stream stream);
+
+/* ---- fp16-pair operands: a cheaper contraction for the same convolutions (nn.Conv2d / nn.ConvTranspose2d of
+ * models/networks.py:14,38 and their autograd backward); engine precision "f16x2" --------------------------------------------------
+ * Operands are fp16 pairs (x = hi + lo, format 1 below).  `products` = 3: al*bh + ah*bl + ah*bh with v_mfma_f32_32x32x16_f16
+ * (up to 22 significant bits per operand, ~1e-6 relative: the forward layers, so OUTPUTS keep the bf16x3 tolerance);
+ * `products` = 2: (ah + al)*bh, two MFMAs instead of three -- the operand that keeps only its hi plane (11 significant bits,
+ * 2^-12 rms rounding) is the weight in the gather / scatter families and `big` in the weight gradient: DECLARED TOLERANCE ~2e-4
+ * relative per layer, used for the backward layers (gradients).  fp16's range is narrow (|x| <= 65504, 2^-24 absolute step below
+ * 2^-14), so a producer of GRADIENT planes multiplies by a power of two (`scale`) and the consuming launch multiplies its
+ * accumulators by out_scale = 1/scale; activations and weights use scale 1 (values saturate at +-65504 instead of overflowing).
+ * Split formats: 0 = bf16 pair (the *_bf16x3 entry points), 1 = fp16 pair (the *_f16* entry points); same buffer sizes.
+ * Every *_fmt producer with format 0 and scale 1 is bit-identical to the entry point without the suffix. */
+#define VP_SPLIT_BF16 0
+#define VP_SPLIT_F16 1
+int vp_split_fmt_f32(const float* x, void* out_split, size_t n, int fmt, float scale, vp_stream stream);
+int vp_nchw_to_nhwc_split_fmt_f32(const float* in, float* out, void* out_split, int B, int C, int H, int W, int fmt, vp_stream stream);
+int vp_bn_act_fwd_split_fmt_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                float* y, void* y_split, int R, int C, int act, float slope, int fmt, vp_stream stream);
+/* dx (fp32, unscaled) and/or dx_split = split(scale * dx) */
+int vp_bn_act_bwd_split_fmt_f32(const float* x, const float* dy, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta,
+                                int R, int C, int act, float slope, int batch_stats, int fmt, float scale,
+                                void* ws, size_t ws_bytes, vp_stream stream);
+int vp_im2col5s2_split_fmt_f32(const float* x, void* out_split, int B, int C, int Hb, int Wb, int nchw, int fmt, vp_stream stream);
+int vp_pack_w_im2col5_split_fmt(const float* w_ref, void* out_split, int Cout, int C, int fmt, vp_stream stream);
+/* the three families; arguments as the *_bf16x3 entry points plus products (2 | 3) and out_scale (workspace queries of the weight
+ * gradient: the *_bf16x3 ones).  The weight gradient exists in the two-product form only. */
+int vp_conv5_gather_f16(const void* big_split, const void* w_p0_split, const float* bias, float* small_out,
+                        int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int act, int products, float out_scale, vp_stream stream);
+int vp_conv_gather_f16(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws,
+                       int Hb, int Wb, int Cbig, int Csmall, int ks, int stride, int act, int products, float out_scale, vp_stream stream);
+int vp_conv5_scatter_f16(const void* small_split, const void* w_p1_split, float* big_out,
+                         int B, int Hs, int Ws, int Csmall, int Cbig, int stride, int products, float out_scale, vp_stream stream);
+int vp_conv_scatter_f16(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb,
+                        int Csmall, int Cbig, int ks, int stride, int products, float out_scale, vp_stream stream);
+int vp_conv5_wgrad_f16x2(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,
+                         int Csmall, int stride, float out_scale, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_conv_wgrad_f16x2(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
+                        int Csmall, int ks, int stride, float out_scale, void* ws, size_t ws_bytes, vp_stream stream);
+/* forward layers with the BatchNorm statistics in the epilogue (as vp_conv5_*_stats_bf16x3; own workspace query because the
+ * launch shapes differ where bf16x3 uses its halo / pipelined kernels) */
+size_t vp_conv5_stats_f16_workspace_bytes(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int stride);
+int vp_conv5_gather_stats_f16(const void* big_split, const void* w_p0_split, float* small_out,
+                              int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int products, float eps, float momentum,
+                              float* mean, float* rstd, float* running_mean, float* running_var,
+                              void* ws, size_t ws_bytes, vp_stream stream);
+int vp_conv5_scatter_stats_f16(const void* small_split, const void* w_p1_split, float* big_out,
+                               int B, int Hs, int Ws, int Csmall, int Cbig, int stride, int products, float eps, float momentum,
+                               float* mean, float* rstd, float* running_mean, float* running_var,
+                               void* ws, size_t ws_bytes, vp_stream stream);
 
 
 /* ---- optimiser step on a flat arena (train_BE.py:62-64,131; train.py:136-140) --------------- */

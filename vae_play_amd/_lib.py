@@ -58,6 +58,24 @@ SIGNATURES = {
     "vp_conv5_stats_workspace_bytes": (c_size_t, [c_int] * 7),
     "vp_conv5_gather_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_conv5_scatter_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_split_fmt_f32": (c_int, [P, P, c_size_t, c_int, c_float, P]),
+    "vp_nchw_to_nhwc_split_fmt_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_bn_act_fwd_split_fmt_f32": (c_int, [P] * 7 + [c_int, c_int, c_int, c_float, c_int, P]),
+    "vp_bn_act_bwd_split_fmt_f32": (c_int, [P] * 10 + [c_int, c_int, c_int, c_float, c_int, c_int, c_float, P, c_size_t, P]),
+    "vp_im2col5s2_split_fmt_f32": (c_int, [P, P] + [c_int] * 6 + [P]),
+    "vp_pack_w_im2col5_split_fmt": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "vp_conv5_gather_f16": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
+    "vp_conv_gather_f16": (c_int, [P, P, P, P] + [c_int] * 11 + [c_float, P]),
+    "vp_conv5_scatter_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
+    "vp_conv_scatter_f16": (c_int, [P, P, P] + [c_int] * 10 + [c_float, P]),
+    "vp_conv5_wgrad_f16x2": (c_int, [P, P, P] + [c_int] * 6 + [c_float, P, c_size_t, P]),
+    "vp_conv_wgrad_f16x2": (c_int, [P, P, P] + [c_int] * 9 + [c_float, P, c_size_t, P]),
+    "vp_conv5_stats_f16_workspace_bytes": (c_size_t, [c_int] * 7),
+    "vp_conv5_gather_stats_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_conv5_scatter_stats_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_conv5_gather_bnbwd_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [P, P, P, P, P, c_int, P, P, P, P, c_size_t, P]),
+    "vp_conv5_scatter_bnbwd_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [P, P, P, P, P, c_int, P, P, P, P, c_size_t, P]),
+    "vp_bn_act_bwd_apply_split_f32": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_int, P]),
     "vp_conv5_wgrad_bf16x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vp_conv5_wgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "vp_bn_act_fwd_split_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ y,
                                                                u16_t* __restrict__ y_split, int R, int C, int rows_per_chunk,
-                                                               int act, float slope, size_t bxs = 0) {
+                                                               int act, float slope, size_t bxs = 0, int sfmt = SPLIT_BF16) {
   x += blockIdx.z * bxs; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
   if (y) y += blockIdx.z * bxs;
   const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = act_apply(bn_pre(v[u][j], mu[j], rs[j], ga[j], be[j]), act, slope);
       if (y) *reinterpret_cast<vp_f32x4*>(y + off) = o;
-      if (y_split) store_split4(y_split, n, off, o[0], o[1], o[2], o[3]);
+      if (y_split) store_split4(y_split, n, off, o[0], o[1], o[2], o[3], sfmt);
     }
   }
   for (; r < r1; r += BN_TY) {
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = act_apply(bn_pre(v[j], mu[j], rs[j], ga[j], be[j]), act, slope);
     if (y) *reinterpret_cast<vp_f32x4*>(y + off) = o;
-    if (y_split) store_split4(y_split, n, off, o[0], o[1], o[2], o[3]);
+    if (y_split) store_split4(y_split, n, off, o[0], o[1], o[2], o[3], sfmt);
   }
 }
 
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
                                                                const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
                                                                float* dx, u16_t* __restrict__ dx_split, int R, int C,
                                                                int rows_per_chunk, float invR, int act, float slope,
-                                                               size_t bxs = 0) {
+                                                               size_t bxs = 0, int sfmt = SPLIT_BF16, float sscale = 1.f) {
   x += blockIdx.z * bxs; dy += blockIdx.z * bxs; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
   sum_g += blockIdx.z * (size_t)C; sum_gx += blockIdx.z * (size_t)C;
   if (dx) dx += blockIdx.z * bxs;
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
       o[j] = ga[j] * rs[j] * (g - (k0[j] + xh * k1[j]));
     }
     if (dx) *reinterpret_cast<vp_f32x4*>(dx + off) = o;
-    if (dx_split) store_split4(dx_split, n, off, o[0], o[1], o[2], o[3]);
+    if (dx_split) store_split4(dx_split, n, off, o[0] * sscale, o[1] * sscale, o[2] * sscale, o[3] * sscale, sfmt);
   };
   int r = r0 + ty;
   for (; r + 3 * BN_TY < r1; r += 4 * BN_TY) {          // eight independent 16-B loads in flight
@@ -460,14 +460,15 @@ int vp_bn_stats_f32(const float* x, int R, int C, float eps, float momentum, flo
 }
 
 static int bn_act_fwd_impl(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
-                           void* y_split, int R, int C, int act, float slope, vp_stream stream) {
+                           void* y_split, int R, int C, int act, float slope, vp_stream stream, int fmt = SPLIT_BF16) {
+  VP_REQUIRE(fmt == SPLIT_BF16 || fmt == SPLIT_F16, "vp_bn_act_fwd_split_fmt_f32: format 0 (bf16 pair) or 1 (fp16 pair)");
   VP_REQUIRE(x && mean && rstd && (y || y_split) && R > 0 && C > 0, "vp_bn_act_fwd: bad arguments");
   VP_REQUIRE(!y_split || C % 4 == 0, "vp_bn_act_fwd_split_f32: C must be a multiple of 4");
   const size_t n = (size_t)R * C;
   if (C % 4 == 0) {
     BnGrid g = bn_apply_grid(R, C);
     hipLaunchKernelGGL(bn_act_fwd_tiled_kernel, dim3(g.chunks_r, g.chunks_c), dim3(256), 0, (hipStream_t)stream, x, mean, rstd,
-                       gamma, beta, y, (u16_t*)y_split, R, C, g.rows_per_chunk, act, slope);
+                       gamma, beta, y, (u16_t*)y_split, R, C, g.rows_per_chunk, act, slope, (size_t)0, fmt);
   } else {
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
                        beta, y, n, C, act, slope, (u16_t*)y_split);
@@ -486,10 +487,17 @@ int vp_bn_act_fwd_split_f32(const float* x, const float* mean, const float* rstd
   return bn_act_fwd_impl(x, mean, rstd, gamma, beta, y, y_split, R, C, act, slope, stream);
 }
 
+int vp_bn_act_fwd_split_fmt_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                float* y, void* y_split, int R, int C, int act, float slope, int fmt, vp_stream stream) {
+  return bn_act_fwd_impl(x, mean, rstd, gamma, beta, y, y_split, R, C, act, slope, stream, fmt);
+}
+
 static int bn_act_bwd_impl(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta, int R, int C, int act,
-                           float slope, int batch_stats, void* ws, size_t ws_bytes, vp_stream stream) {
+                           float slope, int batch_stats, void* ws, size_t ws_bytes, vp_stream stream, int fmt = SPLIT_BF16,
+                           float scale = 1.f) {
   VP_REQUIRE(x && dy && mean && rstd && (dx || dx_split) && ws && R > 0 && C > 0, "vp_bn_act_bwd_f32: bad arguments");
+  VP_REQUIRE((fmt == SPLIT_BF16 || fmt == SPLIT_F16) && scale > 0.f, "vp_bn_act_bwd_split_fmt_f32: format 0 | 1, scale > 0");
   VP_REQUIRE(!dx_split || C % 4 == 0, "vp_bn_act_bwd_split_f32: C must be a multiple of 4");
   if (ws_bytes < vp_bn_workspace_bytes(R, C)) return fail(VP_ERR_WORKSPACE, "vp_bn_act_bwd_f32: workspace too small");
   BnGrid g = bn_grid(R, C);
@@ -510,7 +518,8 @@ static int bn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
   if (C % 4 == 0) {
     BnGrid ga = bn_apply_grid(R, C);
     hipLaunchKernelGGL(bn_act_bwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
-                       (const float*)sum_g, (const float*)sum_gx, dx, (u16_t*)dx_split, R, C, ga.rows_per_chunk, invR, act, slope);
+                       (const float*)sum_g, (const float*)sum_gx, dx, (u16_t*)dx_split, R, C, ga.rows_per_chunk, invR, act, slope,
+                       (size_t)0, fmt, scale);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
                        (const float*)sum_g, (const float*)sum_gx, dx, n, C, invR, act, slope, (u16_t*)dx_split);
@@ -523,6 +532,13 @@ int vp_bn_act_bwd_f32(const float* x, const float* dy, const float* mean, const 
                       int batch_stats, void* ws, size_t ws_bytes, vp_stream stream) {
   VP_REQUIRE(dx, "vp_bn_act_bwd_f32: dx is null");
   return bn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, dx, nullptr, dgamma, dbeta, R, C, act, slope, batch_stats, ws, ws_bytes, stream);
+}
+
+int vp_bn_act_bwd_split_fmt_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta, int R, int C, int act,
+                                float slope, int batch_stats, int fmt, float scale, void* ws, size_t ws_bytes, vp_stream stream) {
+  return bn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, dx, dx_split, dgamma, dbeta, R, C, act, slope, batch_stats, ws, ws_bytes, stream,
+                         fmt, scale);
 }
 
 int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
@@ -592,6 +608,18 @@ int vp_instnorm_act_bwd_f32(const float* x, const float* dy, const float* mean, 
                        (const float*)nullptr, (const float*)sum_g, (const float*)sum_gx, dx, bxs, C, invR, act, slope, (u16_t*)nullptr, bxs);
   }
   return check_launch("vp_instnorm_act_bwd_f32(apply)");
+}
+
+int vp_bn_act_bwd_apply_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, const float* sums, float* dx, void* dx_split, int R, int C, int act, float slope,
+                                  int batch_stats, vp_stream stream) {
+  VP_REQUIRE(x && dy && mean && rstd && sums && (dx || dx_split) && R > 0 && C > 0, "vp_bn_act_bwd_apply_split_f32: bad arguments");
+  VP_REQUIRE(C % 4 == 0, "vp_bn_act_bwd_apply_split_f32: C must be a multiple of 4");
+  const float invR = batch_stats ? 1.f / (float)R : 0.f;
+  const BnGrid ga = bn_apply_grid(R, C);
+  hipLaunchKernelGGL(bn_act_bwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c), dim3(256), 0, (hipStream_t)stream, x, dy, mean, rstd, gamma, beta,
+                     sums, sums + C, dx, (u16_t*)dx_split, R, C, ga.rows_per_chunk, invR, act, slope);
+  return check_launch("vp_bn_act_bwd_apply_split_f32");
 }
 
 int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream) {

@@ -22,7 +22,7 @@ const void* vp_zero_page() {
 
 // out[b][c][r] = in[b][r][c]  (32x32 LDS tile, +1 pad: conflict-free for ds_read_b32 columns)
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols,
-                                 u16_t* __restrict__ out_split, size_t plane) {
+                                 u16_t* __restrict__ out_split, size_t plane, int fmt) {
   __shared__ float tile[32][33];
   const size_t base = (size_t)blockIdx.z * rows * cols;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -39,7 +39,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
       if (out) out[o] = v;
       if (out_split) {
         u16_t h, l;
-        split_f32(v, h, l);
+        split_f32(v, h, l, fmt);
         out_split[o] = h;
         out_split[plane + o] = l;
       }
@@ -48,12 +48,13 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 }
 
 inline int launch_transpose(const float* in, float* out, int B, int rows, int cols, hipStream_t s, const char* what,
-                            void* out_split = nullptr) {
+                            void* out_split = nullptr, int fmt = SPLIT_BF16) {
   VP_REQUIRE(in && (out || out_split) && B > 0 && rows > 0 && cols > 0, "%s: bad arguments", what);
+  VP_REQUIRE(fmt == SPLIT_BF16 || fmt == SPLIT_F16, "%s: format 0 (bf16 pair) or 1 (fp16 pair)", what);
   VP_REQUIRE(B <= 65535, "%s: batch > 65535", what);
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, B);
   VP_REQUIRE(grid.y <= 65535, "%s: too many row tiles", what);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, out, rows, cols, (u16_t*)out_split, (size_t)B * rows * cols);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, in, out, rows, cols, (u16_t*)out_split, (size_t)B * rows * cols, fmt);
   return check_launch(what);
 }
 
@@ -563,6 +564,9 @@ int vp_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W,
 }
 int vp_nchw_to_nhwc_split_f32(const float* in, float* out, void* out_split, int B, int C, int H, int W, vp_stream stream) {
   return launch_transpose(in, out, B, C, H * W, (hipStream_t)stream, "vp_nchw_to_nhwc_split_f32", out_split);
+}
+int vp_nchw_to_nhwc_split_fmt_f32(const float* in, float* out, void* out_split, int B, int C, int H, int W, int fmt, vp_stream stream) {
+  return launch_transpose(in, out, B, C, H * W, (hipStream_t)stream, "vp_nchw_to_nhwc_split_fmt_f32", out_split, fmt);
 }
 int vp_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, vp_stream stream) {
   return launch_transpose(in, out, B, H * W, C, (hipStream_t)stream, "vp_nhwc_to_nchw_f32");

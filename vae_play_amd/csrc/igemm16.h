@@ -63,8 +63,11 @@ struct Lds16 {
 
 // ---- problem descriptors (vector path only: channel counts are multiples of 8) -----------------
 // F family on split planes: A(m=(b,hs,ws), k=(tap,c)) = big[...]; B(n, k) = wp0[n][tap][c]
-template <bool K5>
+template <bool K5, int MODE_ = 0>
 struct ProbF16T {
+  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split)
+  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ != 0;
+  float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
   VP_HD int ks() const { return K5 ? 5 : g.ks; }
@@ -81,8 +84,14 @@ struct ProbF16T {
   // sum((x - pivot)^2)} over the workgroup's valid rows, slab layout [3][N][groups], group = blockIdx.z * row tiles + row tile
   static constexpr bool HAS_STAT = true;
   float* stat = nullptr;
+  // BatchNorm-backward partial sums from the epilogue (nsplit == 1): this launch's output is the gradient dy that enters a
+  // BatchNorm(+ReLU) layer whose convolution output is bx (same layout as out).  Per workgroup and channel {sum g, sum g*xhat}
+  // with xhat = (x - mean) * rstd and g = dy * act'(gamma * xhat + beta): replaces bn_partial_kernel<1>'s read of dy and x.
+  const float* bx = nullptr; const float* bmean = nullptr; const float* brstd = nullptr;
+  const float* bgamma = nullptr; const float* bbeta = nullptr; float* bsum = nullptr; int bact = ACT_NONE;
   struct ZCtx { int k_begin, k_end; };
   struct ARow { int pix_base, h0, w0, valid; };
+  VP_HD bool out_index(int m, int n, const ZCtx&, size_t& idx) const { idx = (size_t)m * N + n; return m < M && n < N; }
   struct BRow { int off, valid; };
   VP_HD void z_setup(int zi, ZCtx& z) const {
     z.k_begin = zi * k_per_split;
@@ -150,6 +159,7 @@ struct ProbF16T {
   VP_HD size_t b_plane() const { return w_plane; }
   VP_HD void store(int m, int n, float v, const ZCtx&) const {
     if (m >= M || n >= N) return;
+    if (F16) v *= alpha;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (nsplit > 1) { atomicAdd(out + (size_t)m * N + n, v); return; }   // 2 addends onto 0: order-independent
 #endif
@@ -160,10 +170,17 @@ struct ProbF16T {
 };
 using ProbF16 = ProbF16T<true>;
 using ProbF16K = ProbF16T<false>;
+using ProbF16X = ProbF16T<true, 1>;
+using ProbF16KX = ProbF16T<false, 1>;
+using ProbF16H = ProbF16T<true, 2>;
+using ProbF16KH = ProbF16T<false, 2>;
 
 // T family on split planes (phase-decomposed transposed conv)
-template <bool K5>
+template <bool K5, int MODE_ = 0>
 struct ProbT16T {
+  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split)
+  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ != 0;
+  float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
   VP_HD int ks() const { return K5 ? 5 : g.ks; }
@@ -177,7 +194,17 @@ struct ProbT16T {
   int xcd_map;
   static constexpr bool HAS_STAT = true;
   float* stat = nullptr;     // see ProbF16T
+  const float* bx = nullptr; const float* bmean = nullptr; const float* brstd = nullptr;
+  const float* bgamma = nullptr; const float* bbeta = nullptr; float* bsum = nullptr; int bact = ACT_NONE;
   struct ZCtx { int k_begin, k_end, ph, pw, th, tw, r0h, r0w, bh, bw; };   // phase geometry as in problems.h ProbT
+  VP_HD bool out_index(int m, int n, const ZCtx& z, size_t& idx) const {
+    if (m >= M || n >= N) { idx = 0; return false; }
+    int b = (int)g.dHW.div((uint32_t)m); int rem = m - b * (g.Hs * g.Ws);
+    int q = (int)g.dW.div((uint32_t)rem), p = rem - q * g.Ws;
+    int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
+    idx = ((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n;
+    return K5 || (oh < g.Hb && ow < g.Wb);
+  }
   struct ARow { int pix_base, q, p, valid; };
   struct BRow { int off, valid; };
   VP_HD void z_setup(int zi, ZCtx& z) const {
@@ -255,6 +282,7 @@ struct ProbT16T {
     int oh = g.stride * q + z.ph, ow = g.stride * p + z.pw;
     if (!K5 && (oh >= g.Hb || ow >= g.Wb)) return;   // odd big sizes: the last phase row/column does not exist
     float* dst = out + ((size_t)(b * g.Hb + oh) * g.Wb + ow) * g.Cb + n;
+    if (F16) v *= alpha;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (nsplit > 1) { atomicAdd(dst, v); return; }
 #endif
@@ -263,10 +291,17 @@ struct ProbT16T {
 };
 using ProbT16 = ProbT16T<true>;
 using ProbT16K = ProbT16T<false>;
+using ProbT16X = ProbT16T<true, 1>;
+using ProbT16KX = ProbT16T<false, 1>;
+using ProbT16H = ProbT16T<true, 2>;
+using ProbT16KH = ProbT16T<false, 2>;
 
 // W family on split planes: slab[split][tap][cs][cb]; both operands pixel-major (KM)
-template <bool K5>
+template <bool K5, int MODE_ = 0>
 struct ProbW16T {
+  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split)
+  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ != 0;
+  float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
   VP_HD int ks() const { return K5 ? 5 : g.ks; }
@@ -313,13 +348,35 @@ struct ProbW16T {
   VP_HD size_t b_plane() const { return big_plane; }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
-    slab[(((size_t)z.split * nt() + z.tap) * M + m) * N + n] = v;
+    slab[(((size_t)z.split * nt() + z.tap) * M + m) * N + n] = F16 ? v * alpha : v;
   }
 };
 using ProbW16 = ProbW16T<true>;
 using ProbW16K = ProbW16T<false>;
+using ProbW16X = ProbW16T<true, 1>;
+using ProbW16KX = ProbW16T<false, 1>;
 
 #if defined(__HIPCC__)
+
+// One fragment pair of the split contraction, fp32 accumulate.
+//   MODE 0 (bf16 pairs): a*b ~= al*bh + ah*bl + ah*bh, three v_mfma_f32_32x32x16_bf16 (16 significant bits per operand);
+//   MODE 2 (fp16 pairs): the same three products with v_mfma_f32_32x32x16_f16 (up to 22 significant bits per operand);
+//   MODE 1 (fp16 pairs): a*b ~= al*bh + ah*bh = a*bh, two MFMAs: operand A keeps hi + lo, operand B only its fp16 hi plane
+//                        (11 bits: 2^-12 rms relative rounding per B element); B's lo plane is not read.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <int MODE>
+__device__ __forceinline__ f32x16_t mfma_split(const bf16x8_t& ah, const bf16x8_t& al, const bf16x8_t& bh, const bf16x8_t& bl, f32x16_t c) {
+  if constexpr (MODE != 0) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, al), __builtin_bit_cast(f16x8_t, bh), c, 0, 0, 0);
+    if constexpr (MODE == 2) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bl), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bh), c, 0, 0, 0);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+  }
+  return c;
+}
 
 template <class P, int NR, bool KM> struct Rows16A;
 template <class P, int NR> struct Rows16A<P, NR, false> { typename P::ARow r[NR]; };
@@ -392,6 +449,49 @@ __device__ __forceinline__ void epilogue_stats32(float* __restrict__ stat, int g
     stat[(1 * (size_t)N + n) * groups + group] = s;
     stat[(2 * (size_t)N + n) * groups + group] = q;
   }
+}
+
+// BatchNorm-backward partial sums of the workgroup's output tile (see ProbF16T::bx): same reduction scheme as epilogue_stats32.
+// The pre-activation is evaluated with bn.hip's bn_pre() expression so that the mask is bit-consistent with the forward pass.
+template <class P, int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void epilogue_bnbwd32(const P& p, const typename P::ZCtx& z, int groups, int group, const f32x16_t (&acc)[TM][TN],
+                                                 unsigned char* lds, int m0, int n0, int wm, int wn, int li, int lh, int tid) {
+  float* red = reinterpret_cast<float*>(lds);      // [WM][BN][2]
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * (BN / WN) + 32 * j + li, n = n0 + col;
+    const bool nok = n < p.N;
+    const float mu = nok ? p.bmean[n] : 0.f, rs = nok ? p.brstd[n] : 0.f;
+    const float ga = (nok && p.bgamma) ? p.bgamma[n] : 1.f, be = (nok && p.bbeta) ? p.bbeta[n] : 0.f;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        size_t idx;
+        if (p.out_index(m, n, z, idx)) {
+          const float xh = (p.bx[idx] - mu) * rs;
+          const float pre = __builtin_fmaf(ga, xh, be);
+          const float g = (p.bact == ACT_RELU && !(pre > 0.f)) ? 0.f : acc[i][j][r];
+          s += g;
+          q += g * xh;
+        }
+      }
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (lh == 0) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < p.N) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+    const size_t n = (size_t)(n0 + tid);
+    p.bsum[(0 * (size_t)p.N + n) * groups + group] = s;
+    p.bsum[(1 * (size_t)p.N + n) * groups + group] = q;
+  }
+  __syncthreads();
 }
 
 template <class P, int BM, int BN, int WM, int WN, int BKT, bool FAST>
@@ -514,13 +614,13 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 #pragma unroll
           for (int j = 0; j < CPH; ++j) {
             sb[i * CPT + j] = ld16(b0 + (l4 * CPH + j) * 8);
-            sb[i * CPT + CPH + j] = ld16(b1 + (l4 * CPH + j) * 8);
+            if constexpr (!P::X2) sb[i * CPT + CPH + j] = ld16(b1 + (l4 * CPH + j) * 8);      // X2: B's lo plane is never read
           }
         } else {
 #pragma unroll
           for (int j = 0; j < CPH; ++j) {
             sb[i * CPT + j] = p.template b_load<false>(rb.r[i], k0, (l4 * CPH + j) * 8, 0, z);
-            sb[i * CPT + CPH + j] = p.template b_load<false>(rb.r[i], k0, (l4 * CPH + j) * 8, 1, z);
+            if constexpr (!P::X2) sb[i * CPT + CPH + j] = p.template b_load<false>(rb.r[i], k0, (l4 * CPH + j) * 8, 1, z);
           }
         }
       }
@@ -534,12 +634,14 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
         const u16* b1 = ok ? p.b_ptr() + p.b_plane() + off + n0 : reinterpret_cast<const u16*>(p.zero);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+          if (P::X2 && TP * i >= V) continue;     // (compile-time after unrolling) chunks of the lo plane: not read by X2
           const int ch = c0 + TP * i;
           sb[i] = ld16((ch / V ? b1 : b0) + (ch % V) * 8);
         }
       } else {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+          if (P::X2 && TP * i >= V) continue;
           const int ch = c0 + TP * i;
           sb[i] = p.b_load_km(k0 + kr, n0 + (ch % V) * 8, ch / V, z);
         }
@@ -574,13 +676,14 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
         for (int j = 0; j < CPH; ++j) {
           unsigned char* dst = Bs + (srow + RPP * i) * MKS + (l4 * CPH + j) * 16;
           *reinterpret_cast<u32x4_t*>(dst) = sb[i * CPT + j];
-          *reinterpret_cast<u32x4_t*>(dst + B_PLANE) = sb[i * CPT + CPH + j];
+          if constexpr (!P::X2) *reinterpret_cast<u32x4_t*>(dst + B_PLANE) = sb[i * CPT + CPH + j];
         }
     } else {
       constexpr int V = BN / 8, TP = 256 / BKT, S = KmStride<BN>::bytes;
       const int kr = tid / TP, c0 = tid % TP;
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
+        if (P::X2 && TP * i >= V) continue;
         const int ch = c0 + TP * i;
         *reinterpret_cast<u32x4_t*>(Bs + (ch / V) * B_PLANE + kr * S + (ch % V) * 16) = sb[i];
       }
@@ -619,15 +722,14 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = frag16<BN, P::B_KM, BKT>(Bs, brow0 + 32 * j, s, li, lh, lane);
-        bl[j] = frag16<BN, P::B_KM, BKT>(Bs + B_PLANE, brow0 + 32 * j, s, li, lh, lane);
+        if constexpr (P::X2) bl[j] = bh[j];      // not read by the two-product form
+        else bl[j] = frag16<BN, P::B_KM, BKT>(Bs + B_PLANE, brow0 + 32 * j, s, li, lh, lane);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_split<P::MODE>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
         }
     }
     __syncthreads();
@@ -641,6 +743,9 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
     if (p.stat)      // (workgroup-uniform) every wave is past its last LDS read: the loop ends with a barrier
       epilogue_stats32<BM, BN, WM, WN, TM, TN>(p.stat, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, p.M, p.N, acc, lds, m0, n0,
                                                wm, wn, li, lh, tid);
+    if (p.bsum)
+      epilogue_bnbwd32<P, BM, BN, WM, WN, TM, TN>(p, z, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, acc, lds, m0, n0,
+                                                  wm, wn, li, lh, tid);
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -802,9 +907,7 @@ __global__ void __launch_bounds__(256) igemm16_dma_kernel(const P p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_split<P::MODE>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed

@@ -316,6 +316,11 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) igemm16p_kernel(const P p)
     epilogue_stats32<BM, BN, WM, WN, TM, TN>(p.stat, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, p.M, p.N, acc, lds, m0, n0,
                                              wm, wn, li, lh, tid);
   }
+  if (p.bsum) {      // BatchNorm-backward partial sums of the tile (igemm16.h epilogue_bnbwd32)
+    __syncthreads();
+    epilogue_bnbwd32<P, BM, BN, WM, WN, TM, TN>(p, z, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, acc, lds, m0, n0,
+                                                wm, wn, li, lh, tid);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll

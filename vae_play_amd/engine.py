@@ -16,6 +16,7 @@ with the model/loss of models/networks.py (Encoder :72-78, reparameterize :228-2
 """
 from __future__ import annotations
 
+import math
 import os
 from ctypes import c_void_p
 from typing import Callable, Dict, List, Optional, Tuple
@@ -101,14 +102,24 @@ class FusedVAEStep:
     """
 
     def __init__(self, vae: VAE, optimizer, batch_size: int, img_size: int, channels: int, group=None,
-                 precision: str = "bf16x3"):
+                 precision: str = "bf16x3", grad_scale16: float = 4096.0):
         """precision: "f32"    -- every contraction on v_mfma_f32_32x32x2_f32 (exact fp32, ~1e-6 parity);
                       "bf16x3" -- 5x5 convolutions whose channel counts are multiples of 8 run on the
                                   split-bf16 kernel (3 bf16 MFMAs per product, fp32 accumulate, ~1e-5 parity);
-                                  edge layers and dense layers stay on the f32 kernels."""
-        if precision not in ("f32", "bf16x3"):
-            raise ValueError("precision must be 'f32' or 'bf16x3'")
+                                  edge layers and dense layers stay on the f32 kernels;
+                      "f16x2"  -- the same plan with those convolutions on fp16-pair operands: forward layers with 3 fp16 MFMAs
+                                  per product (outputs keep the ~1e-5 parity), BACKWARD layers (input and weight gradients) with
+                                  2 (DECLARED tolerance ~2e-4 relative per layer on gradients; the final convolution's narrow
+                                  side stays on its bf16x3 kernels).  ``grad_scale16`` (a power of two) is the factor
+                                  gradient operands are multiplied by before they are written as fp16 pairs -- the consuming
+                                  launch divides it out of its accumulators, so every fp32 buffer and the gradient arena hold
+                                  true values; gradient elements beyond 65504 / grad_scale16 saturate."""
+        if precision not in ("f32", "bf16x3", "f16x2"):
+            raise ValueError("precision must be 'f32', 'bf16x3' or 'f16x2'")
+        if precision == "f16x2" and not (grad_scale16 > 0 and math.log2(grad_scale16).is_integer()):
+            raise ValueError("grad_scale16 must be a positive power of two")
         self.precision = precision
+        self.grad_scale16 = float(grad_scale16)
         self.vae, self.opt, self.B, self.S, self.C = vae, optimizer, batch_size, img_size, channels
         self.Z, self.L = vae.z_size, vae.iter_level
         self.group = group
@@ -159,9 +170,33 @@ class FusedVAEStep:
         # Weight gradients go to a side stream (bf16x3 plans): they only feed the optimiser, so they can run underneath
         # the next layer's HBM-bound BatchNorm backward.  The split output gradient they read is ping-ponged between
         # two buffers; before a buffer is rewritten the main stream waits for the weight gradient that read it.
-        side_on = self.precision == "bf16x3"
-        x3 = self.precision == "bf16x3"
+        x2 = self.precision == "f16x2"                 # fp16-pair planes + the *_f16x2 launches (same plan structure)
+        x3 = self.precision in ("bf16x3", "f16x2")
+        side_on = x3
+        FMT = 1 if x2 else 0                           # VP_SPLIT_F16 | VP_SPLIT_BF16
+        GS = self.grad_scale16 if x2 else 1.0          # scale of gradient planes; 1/GS in the launches that consume them
         n_side = [0]
+
+        # fp16 plans: forward layers contract with three products (outputs keep the bf16x3 tolerance), backward layers with two
+        FWD_PRODUCTS = int(os.environ.get("VP_F16_FWD_PRODUCTS", "3"))     # A/B knob (2: the forward also on two MFMAs)
+
+        def add_gather(plan, a_s, w_s, bias, out, geom, act, alpha=1.0, products=2, **kw):
+            if x2:
+                plan.add("vp_conv5_gather_f16", P(a_s), P(w_s), P(bias), P(out), *geom, act, products, alpha, **kw)
+            else:
+                plan.add("vp_conv5_gather_bf16x3", P(a_s), P(w_s), P(bias), P(out), *geom, act, **kw)
+
+        def add_scatter(plan, a_s, w_s, out, geom, alpha=1.0, products=2, **kw):
+            if x2:
+                plan.add("vp_conv5_scatter_f16", P(a_s), P(w_s), P(out), *geom, products, alpha, **kw)
+            else:
+                plan.add("vp_conv5_scatter_bf16x3", P(a_s), P(w_s), P(out), *geom, **kw)
+
+        def add_wgrad(plan, big_s, small_s, dw, geom, ws, alpha=1.0, **kw):
+            if x2:
+                plan.add("vp_conv5_wgrad_f16x2", P(big_s), P(small_s), P(dw), *geom, alpha, P(ws), ws.numel() * 4, **kw)
+            else:
+                plan.add("vp_conv5_wgrad_bf16x3", P(big_s), P(small_s), P(dw), *geom, P(ws), ws.numel() * 4, **kw)
 
         def side_slot():
             if not side_on:
@@ -174,9 +209,10 @@ class FusedVAEStep:
         k_pack = side_slot() if os.environ.get("VP_SIDE_PACK", "1") != "0" else None
         first_pack_jobs = []
 
-        def pack(weight, p0, p1, Cs, Cb, split, Cs_pad=0, first=False):
+        def pack(weight, p0, p1, Cs, Cb, split, Cs_pad=0, first=False, bf16=False):
+            """split: planes in the plan's format (bf16=True forces bf16 pairs: the final conv's kernels read those)"""
             (first_pack_jobs if (first and k_pack is not None) else pack_jobs).append(_lib.PackJob(weight.data_ptr(), p0.data_ptr() if p0 is not None else None,
-                                          p1.data_ptr() if p1 is not None else None, Cs, Cb, Cs_pad, 1 if split else 0))
+                                          p1.data_ptr() if p1 is not None else None, Cs, Cb, Cs_pad, (2 if (x2 and not bf16) else 1) if split else 0))
 
         def grad_of(p: torch.nn.Parameter) -> torch.Tensor:
             if p.grad is None:
@@ -202,23 +238,61 @@ class FusedVAEStep:
             if conv is not None:
                 family, name, lead, geom, fl, ctag = conv
                 qgeom = geom if family == 0 else (geom[0], geom[1], geom[2], geom[4], geom[3], geom[5])   # query takes (Cbig, Csmall)
-                nst = lib.vp_conv5_stats_workspace_bytes(family, *qgeom) if fuse_stats else 0
+                query = lib.vp_conv5_stats_f16_workspace_bytes if x2 else lib.vp_conv5_stats_workspace_bytes
+                nst = query(family, *qgeom) if fuse_stats else 0
                 if nst:
                     st = self._ws(f"{tag}.statws", nst)
-                    fwd.add(name.replace("_bf16x3", "_stats_bf16x3"), *lead, *geom, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
-                            P(bn_mod.running_var), P(st), st.numel() * 4, flops=fl, tag=ctag)
+                    fwd.add(name.replace("_bf16x3", "_stats_f16" if x2 else "_stats_bf16x3"), *lead, *geom, *((FWD_PRODUCTS,) if x2 else ()),
+                            eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean), P(bn_mod.running_var), P(st), st.numel() * 4,
+                            flops=fl, tag=ctag)
                     fused = True
                 else:
                     extra = (None,) if family == 0 else ()
-                    fwd.add(name, lead[0], lead[1], *extra, lead[2], *geom, *((_ACT_NONE,) if family == 0 else ()), flops=fl, tag=ctag)
+                    tail = ((_ACT_NONE,) if family == 0 else ()) + ((FWD_PRODUCTS, 1.0) if x2 else ())
+                    fwd.add(name.replace("_bf16x3", "_f16") if x2 else name, lead[0], lead[1], *extra, lead[2], *geom, *tail, flops=fl, tag=ctag)
             if not fused:
                 fwd.add("vp_bn_stats_f32", P(x_buf), R, Cn, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
                         P(bn_mod.running_var), P(ws), ws.numel() * 4)
-            fwd.add("vp_bn_act_fwd_split_f32", P(x_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(y_buf),
-                    P(y_split), R, Cn, _ACT_RELU, 0.0)
+            if x2 and y_split is not None:
+                fwd.add("vp_bn_act_fwd_split_fmt_f32", P(x_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(y_buf),
+                        P(y_split), R, Cn, _ACT_RELU, 0.0, FMT)
+            else:
+                fwd.add("vp_bn_act_fwd_split_f32", P(x_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(y_buf),
+                        P(y_split), R, Cn, _ACT_RELU, 0.0)
             return mean, rstd, ws
 
-        def bn_block_bwd(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None):
+        # BatchNorm-backward sums from the input-gradient convolution's epilogue: measured NO gain on the concurrent schedule (the
+        # HBM-bound partial-sum pass it removes already hides under the side stream's weight gradient, profiles/r02_notes.md
+        # section 4), so it is off by default.  A/B knob: 0 | 1 | f (gather launches only) | t (scatter only) | k=<layer,...>
+        bnbwd_mode = os.environ.get("VP_FUSE_BN_BWD", "0")
+        fuse_bnbwd = x3 and not x2 and bnbwd_mode != "0"
+
+        def dgrad_bnbwd(plan, family, name, lead, geom, fl, tag, bn_x, mean, rstd, bn_mod, key):
+            """The input-gradient convolution whose output is dy of a BatchNorm + ReLU layer (conv output ``bn_x``): when the
+            launch shape can emit epilogue sums, ONE call (vp_conv5_*_bnbwd_bf16x3) also produces sum g, sum g*xhat and the
+            affine gradients, and the BatchNorm backward that follows only applies them.  Returns the sums buffer or None."""
+            qgeom = geom if family == 0 else (geom[0], geom[1], geom[2], geom[4], geom[3], geom[5])
+            nb = lib.vp_conv5_stats_workspace_bytes(family, *qgeom) if fuse_bnbwd else 0
+            if (bnbwd_mode == "f" and family != 0) or (bnbwd_mode == "t" and family != 1) or (bnbwd_mode.startswith("k=") and key not in bnbwd_mode[2:].split(",")):
+                nb = 0
+            if not nb:
+                return None
+            Cn = geom[4]                                        # channels of the convolution's output
+            sums, wsb = self._buf(f"{key}.bnsums", 2 * Cn), self._ws(f"{key}.bnbwdws", nb)
+            plan.add(name.replace("_bf16x3", "_bnbwd_bf16x3"), *lead, *geom, P(bn_x), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
+                     _ACT_RELU, P(sums), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), P(wsb), wsb.numel() * 4, flops=fl, tag=tag)
+            return sums
+
+        def bn_block_bwd(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None, sums=None):
+            if sums is not None:
+                bwd.add("vp_bn_act_bwd_apply_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(sums),
+                        P(dx_buf), P(dx_split), R, Cn, _ACT_RELU, 0.0, 1)
+                return
+            if x2 and dx_split is not None:      # gradient planes: fp16 pairs of GS * dx
+                bwd.add("vp_bn_act_bwd_split_fmt_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
+                        P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1, FMT, GS,
+                        P(ws), ws.numel() * 4)
+                return
             bwd.add("vp_bn_act_bwd_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
                     P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1,
                     P(ws), ws.numel() * 4)
@@ -253,10 +327,16 @@ class FusedVAEStep:
                 xcol = self._sbuf("enc0.xcol", B * Hs * Hs * KC)
                 w0s = self._sbuf("enc0.w0s", Cout * KC)
                 self._enc0 = (xcol, KC)
-                fwd.add("vp_im2col5s2_split_f32", P(self.x_nchw), P(xcol), B, Cin, S, S, 1)
-                fwd.add("vp_pack_w_im2col5_split", P(blk.conv.weight), P(w0s), Cout, Cin)
-                fwd.add("vp_conv_gather_bf16x3", P(xcol), P(w0s), None, P(c), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, _ACT_NONE,
-                        flops=fl, tag="enc0.fwd")
+                if x2:
+                    fwd.add("vp_im2col5s2_split_fmt_f32", P(self.x_nchw), P(xcol), B, Cin, S, S, 1, FMT)
+                    fwd.add("vp_pack_w_im2col5_split_fmt", P(blk.conv.weight), P(w0s), Cout, Cin, FMT)
+                    fwd.add("vp_conv_gather_f16", P(xcol), P(w0s), None, P(c), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, _ACT_NONE, FWD_PRODUCTS, 1.0,
+                            flops=fl, tag="enc0.fwd")
+                else:
+                    fwd.add("vp_im2col5s2_split_f32", P(self.x_nchw), P(xcol), B, Cin, S, S, 1)
+                    fwd.add("vp_pack_w_im2col5_split", P(blk.conv.weight), P(w0s), Cout, Cin)
+                    fwd.add("vp_conv_gather_bf16x3", P(xcol), P(w0s), None, P(c), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, _ACT_NONE,
+                            flops=fl, tag="enc0.fwd")
                 p1 = None
             elif enc16[i]:
                 p0 = self._sbuf(f"enc{i}.p0s", Cout * 25 * Cin)
@@ -308,7 +388,10 @@ class FusedVAEStep:
         dec16 = [use16(dec_ch[i], dec_ch[i + 1]) for i in range(L)]
         dn = None if dec16[0] else self._buf("dec.in", B * F1)
         dn_s = self._sbuf("dec.in_s", B * F1) if dec16[0] else None
-        fwd.add("vp_nchw_to_nhwc_split_f32", P(db), P(dn), P(dn_s), B, dsize, 8, 8)
+        if x2:
+            fwd.add("vp_nchw_to_nhwc_split_fmt_f32", P(db), P(dn), P(dn_s), B, dsize, 8, 8, FMT)
+        else:
+            fwd.add("vp_nchw_to_nhwc_split_f32", P(db), P(dn), P(dn_s), B, dsize, 8, 8)
 
         dec_in = [dn]
         dec_in_s = [dn_s]
@@ -350,8 +433,8 @@ class FusedVAEStep:
         if dec_in_s[-1] is not None:
             fp0s = self._sbuf("fin.p0s", C * 25 * Cf)
             pack(fin.weight, fp0s, None, C, Cf, True)
-            fwd.add("vp_conv5_gather_bf16x3", P(dec_in_s[-1]), P(fp0s), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, 1, _ACT_SIGMOID,
-                    flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
+            add_gather(fwd, dec_in_s[-1], fp0s, fin.bias, xt_nhwc, (B, S, S, Cf, C, 1), _ACT_SIGMOID, products=FWD_PRODUCTS,
+                       flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
         elif x3 and Cf == 64 and C in (1, 3) and os.environ.get("VP_TAPN", "1") != "0":
             # split-bf16 on the matrix cores, taps folded into the MFMA columns (the exact-f32 plan keeps the VALU kernel)
             fwd.add("vp_conv5_smallout_bf16x3", P(dec_in[-1]), P(fp0), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, _ACT_SIGMOID,
@@ -376,7 +459,7 @@ class FusedVAEStep:
         if fin16:
             dlogit_s = self._sbuf("g.dlogit_s", B * S * S * 8)
             fp1s = self._sbuf("fin.p1s", Cf * 25 * 8)
-            pack(fin.weight, None, fp1s, C, Cf, True, 8)
+            pack(fin.weight, None, fp1s, C, Cf, True, 8, bf16=True)       # bf16 pairs: read by the halo kernel in every mode
             bwd.add("vp_bce_sigmoid_bwd_pad_split_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), P(dlogit_s), B * S * S, C, 8)
         else:
             bwd.add("vp_bce_sigmoid_bwd_f32", P(xt_nhwc), P(x_nhwc), inv_b, P(dlogit), n_pix)
@@ -411,6 +494,7 @@ class FusedVAEStep:
             if gs_last[k] is not None:
                 plan.wait_side(gs_last[k])
             return k
+        pend = None                 # BatchNorm-backward sums the previous input-gradient convolution already produced
         for i in range(L - 1, -1, -1):
             blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws = dec_rec[i]
             R = B * 4 * Hs * Hs
@@ -418,13 +502,20 @@ class FusedVAEStep:
             if dec16[i]:
                 k = next_gs(bwd)
                 gS = gS2[k]
-                bn_block_bwd(tbuf, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)      # gS = d t_i (split)
+                bn_block_bwd(tbuf, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS, sums=pend)  # gS = d t_i (split)
                 gs_last[k] = side_slot()
-                bwd.add("vp_conv5_wgrad_bf16x3", P(gS), P(dec_in_s[i]), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2,
-                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"dec{i}.wgrad", side=gs_last[k])
-                bwd.add("vp_conv5_gather_bf16x3", P(gS), P(p0), None, P(cur), B, Hs, Hs, Cout, Cin, 2, _ACT_NONE,
-                        flops=fl, tag=f"dec{i}.dgrad")                                     # cur = d input_i
+                add_wgrad(bwd, gS, dec_in_s[i], grad_of(blk.conv.weight), (B, Hs, Hs, Cout, Cin, 2), ws_wg, 1.0 / GS,
+                          flops=fl, tag=f"dec{i}.wgrad", side=gs_last[k])
+                pend = None
+                if i > 0 and dec16[i - 1]:      # cur = d input_i is dy of block i-1's BatchNorm + ReLU
+                    nblk, _, _, _, _, ntbuf, nmean, nrstd, _ = dec_rec[i - 1]
+                    pend = dgrad_bnbwd(bwd, 0, "vp_conv5_gather_bf16x3", (P(gS), P(p0), P(cur)), (B, Hs, Hs, Cout, Cin, 2), fl,
+                                       f"dec{i}.dgrad", ntbuf, nmean, nrstd, nblk.bn, f"dec{i - 1}")
+                if pend is None:
+                    add_gather(bwd, gS, p0, None, cur, (B, Hs, Hs, Cout, Cin, 2), _ACT_NONE, 1.0 / GS,
+                               flops=fl, tag=f"dec{i}.dgrad")                              # cur = d input_i
             else:
+                assert pend is None
                 bn_block_bwd(tbuf, cur, other, R, Cout, blk.bn, mean, rstd, ws)          # other = d t_i
                 bwd.add("vp_conv5_wgrad_f32", P(other), P(dec_in[i]), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2,
                         P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"dec{i}.wgrad")
@@ -457,7 +548,16 @@ class FusedVAEStep:
         bwd = bwd_b
         dh = self._buf("g.dh", B * 1024)
 
-        def bn_block_bwd2(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None):
+        def bn_block_bwd2(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None, sums=None):
+            if sums is not None:
+                bwd.add("vp_bn_act_bwd_apply_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(sums),
+                        P(dx_buf), P(dx_split), R, Cn, _ACT_RELU, 0.0, 1)
+                return
+            if x2 and dx_split is not None:      # gradient planes: fp16 pairs of GS * dx
+                bwd.add("vp_bn_act_bwd_split_fmt_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
+                        P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1, FMT, GS,
+                        P(ws), ws.numel() * 4)
+                return
             bwd.add("vp_bn_act_bwd_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
                     P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1,
                     P(ws), ws.numel() * 4)
@@ -472,6 +572,7 @@ class FusedVAEStep:
         self._bwd_b_dense_done = len(bwd.calls)
         bwd.add("vp_nchw_to_nhwc_f32", P(gA), P(gB), B, size, 8, 8)
         cur, other = gB, gA
+        pend = None
         for i in range(L - 1, -1, -1):
             blk, Cin, Cout, Hs, p1, c, mean, rstd, ws = enc_rec[i]
             R = B * Hs * Hs
@@ -480,27 +581,38 @@ class FusedVAEStep:
                 xcol, KC = self._enc0
                 k = next_gs(bwd)
                 gS = gS2[k]
-                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)        # gS = d c_0 (split)
+                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS, sums=pend)  # gS = d c_0 (split)
                 dwc = self._buf("enc0.dwc", Cout * KC)
                 ws0 = self._ws("enc0.wgws", lib.vp_conv_wgrad_bf16x3_workspace_bytes(B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1))
                 gs_last[k] = side_slot()
-                bwd.add("vp_conv_wgrad_bf16x3", P(xcol), P(gS), P(dwc), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, P(ws0), ws0.numel() * 4,
-                        flops=fl, tag="enc0.wgrad", side=gs_last[k])
+                if x2:
+                    bwd.add("vp_conv_wgrad_f16x2", P(xcol), P(gS), P(dwc), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, 1.0 / GS, P(ws0), ws0.numel() * 4,
+                            flops=fl, tag="enc0.wgrad", side=gs_last[k])
+                else:
+                    bwd.add("vp_conv_wgrad_bf16x3", P(xcol), P(gS), P(dwc), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, P(ws0), ws0.numel() * 4,
+                            flops=fl, tag="enc0.wgrad", side=gs_last[k])
                 bwd.add("vp_unpack_dw_im2col5_f32", P(dwc), P(grad_of(blk.conv.weight)), Cout, Cin, side=side_slot())
             elif enc16[i]:
                 k = next_gs(bwd)
                 gS = gS2[k]
-                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)        # gS = d c_i (split)
+                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS, sums=pend)  # gS = d c_i (split)
                 gs_last[k] = side_slot()
-                bwd.add("vp_conv5_wgrad_bf16x3", P(enc_in_s[i]), P(gS), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,
-                        P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"enc{i}.wgrad", side=gs_last[k])
-                if i > 0:
-                    bwd.add("vp_conv5_scatter_bf16x3", P(gS), P(p1), P(cur), B, Hs, Hs, Cout, Cin, 2,
-                            flops=fl, tag=f"enc{i}.dgrad")                                 # cur = d a_{i-1}
+                add_wgrad(bwd, enc_in_s[i], gS, grad_of(blk.conv.weight), (B, Hs, Hs, Cin, Cout, 2), ws_wg, 1.0 / GS,
+                          flops=fl, tag=f"enc{i}.wgrad", side=gs_last[k])
+                pend = None
+                if i > 0:                       # cur = d a_{i-1} is dy of block i-1's BatchNorm + ReLU
+                    if enc16[i - 1] or (i == 1 and enc0_cols):
+                        nblk, _, _, _, _, nc, nmean, nrstd, _ = enc_rec[i - 1]
+                        pend = dgrad_bnbwd(bwd, 1, "vp_conv5_scatter_bf16x3", (P(gS), P(p1), P(cur)), (B, Hs, Hs, Cout, Cin, 2), fl,
+                                           f"enc{i}.dgrad", nc, nmean, nrstd, nblk.bn, f"enc{i - 1}")
+                    if pend is None:
+                        add_scatter(bwd, gS, p1, cur, (B, Hs, Hs, Cout, Cin, 2), 1.0 / GS,
+                                    flops=fl, tag=f"enc{i}.dgrad")                         # cur = d a_{i-1}
                 if i == max(L - 2, 1):
                     # the gradients of encoder.conv[i:] (16.4 of the 17 MB of conv parameters at config 3) are issued: third bucket
                     self._bwd_b_enc_tail, self._enc_tail_first = len(bwd.calls), i
             else:
+                assert pend is None
                 bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)            # other = d c_i
                 # side stream only for the last layer of the walk (i == 0): nothing rewrites `other` after it
                 bwd.add("vp_conv5_wgrad_f32", P(enc_in[i]), P(other), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,

@@ -425,10 +425,17 @@ def empty_split(n: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty((2, n), dtype=torch.int16, device=like.device)
 
 
-def split_f32(x: torch.Tensor) -> torch.Tensor:
+SPLIT_BF16, SPLIT_F16 = 0, 1     # VP_SPLIT_* of include/vaeplay_hip.h: bf16 pair ("bf16x3" kernels) | fp16 pair ("f16x2" kernels)
+
+
+def split_f32(x: torch.Tensor, fmt: int = SPLIT_BF16, scale: float = 1.0) -> torch.Tensor:
+    """Split planes of ``scale * x`` (scale: a power of two; gradients on the fp16-pair format, see the header)."""
     x = x if x.is_contiguous() or _is_nhwc(x) else x.contiguous()
     out = empty_split(x.numel(), x)
-    _lib.call("vp_split_f32", _p(x), _pv(out), x.numel(), _stream())
+    if fmt == SPLIT_BF16 and scale == 1.0:
+        _lib.call("vp_split_f32", _p(x), _pv(out), x.numel(), _stream())
+    else:
+        _lib.call("vp_split_fmt_f32", _p(x), _pv(out), x.numel(), fmt, scale, _stream())
     return out
 
 
@@ -441,18 +448,24 @@ def split_pad(x: torch.Tensor, cpad: int) -> torch.Tensor:
     return out
 
 
-def unsplit(s: torch.Tensor) -> torch.Tensor:
+def unsplit(s: torch.Tensor, fmt: int = SPLIT_BF16) -> torch.Tensor:
     """hi + lo as fp32 (test helper; torch ops)."""
-    return s[0].view(torch.bfloat16).float() + s[1].view(torch.bfloat16).float()
+    dt = torch.float16 if fmt == SPLIT_F16 else torch.bfloat16
+    return s[0].view(dt).float() + s[1].view(dt).float()
 
 
-def pack_w5_split(w_ref: torch.Tensor, want_p0: bool, want_p1: bool):
+def pack_w5_split(w_ref: torch.Tensor, want_p0: bool, want_p1: bool, fmt: int = SPLIT_BF16):
     Cs, Cb = w_ref.shape[0], w_ref.shape[1]
     w_ref = w_ref.contiguous()
     n = Cs * Cb * 25
     p0 = empty_split(n, w_ref) if want_p0 else None
     p1 = empty_split(n, w_ref) if want_p1 else None
-    _lib.call("vp_pack_w5_split", _p(w_ref), _pv(p0), _pv(p1), Cs, Cb, _stream())
+    if fmt == SPLIT_BF16:
+        _lib.call("vp_pack_w5_split", _p(w_ref), _pv(p0), _pv(p1), Cs, Cb, _stream())
+    else:
+        job = (_lib.PackJob * 1)(_lib.PackJob(w_ref.data_ptr(), p0.data_ptr() if want_p0 else None, p1.data_ptr() if want_p1 else None,
+                                               Cs, Cb, Cs, 2))
+        _lib.call("vp_pack_w5_batch", job, 1, _stream())
     return p0, p1
 
 
@@ -489,6 +502,36 @@ def conv5_wgrad_bf16x3(big_split, shape_big, small_split, shape_small, stride: i
     ws = torch.empty(max(4, (nbytes + 3) // 4), dtype=torch.float32, device=big_split.device)
     dw = torch.empty((Cs, Cb, 5, 5), dtype=torch.float32, device=big_split.device)
     _lib.call("vp_conv5_wgrad_bf16x3", _pv(big_split), _pv(small_split), _p(dw), B, Hs, Ws, Cb, Cs, stride, _p(ws), ws.numel() * 4, _stream())
+    return dw
+
+
+# ---- fp16-pair operands: products = 3 (~1e-6 relative) or 2 (two MFMAs per fragment pair, declared tolerance ~2e-4 per layer) ----
+def conv5_gather_f16(big_split, shape_big, w_p0_split, Cs: int, bias, stride: int, act: int = ACT_NONE, products: int = 2,
+                     out_scale: float = 1.0):
+    B, Cb, Hb, Wb = shape_big
+    Hs, Ws = Hb // stride, Wb // stride
+    out = torch.empty((B, Cs, Hs, Ws), dtype=torch.float32, device=big_split.device, memory_format=torch.channels_last)
+    _lib.call("vp_conv5_gather_f16", _pv(big_split), _pv(w_p0_split), _p(bias), _p(out), B, Hs, Ws, Cb, Cs, stride, act, products, out_scale,
+              _stream())
+    return out
+
+
+def conv5_scatter_f16(small_split, shape_small, w_p1_split, Cb: int, stride: int, products: int = 2, out_scale: float = 1.0):
+    B, Cs, Hs, Ws = shape_small
+    out = torch.empty((B, Cb, Hs * stride, Ws * stride), dtype=torch.float32, device=small_split.device,
+                      memory_format=torch.channels_last)
+    _lib.call("vp_conv5_scatter_f16", _pv(small_split), _pv(w_p1_split), _p(out), B, Hs, Ws, Cs, Cb, stride, products, out_scale, _stream())
+    return out
+
+
+def conv5_wgrad_f16x2(big_split, shape_big, small_split, shape_small, stride: int, out_scale: float = 1.0):
+    B, Cb, Hb, Wb = shape_big
+    _, Cs, Hs, Ws = shape_small
+    nbytes = _lib.load().vp_conv5_wgrad_bf16x3_workspace_bytes(B, Hs, Ws, Cb, Cs, stride)
+    ws = torch.empty(max(4, (nbytes + 3) // 4), dtype=torch.float32, device=big_split.device)
+    dw = torch.empty((Cs, Cb, 5, 5), dtype=torch.float32, device=big_split.device)
+    _lib.call("vp_conv5_wgrad_f16x2", _pv(big_split), _pv(small_split), _p(dw), B, Hs, Ws, Cb, Cs, stride, out_scale, _p(ws),
+              ws.numel() * 4, _stream())
     return dw
 
 
