@@ -359,6 +359,12 @@ int vp_conv5_scatter_stats_f16(const void* small_split, const void* w_p1_split, 
  * (1/world_size after a sum all-reduce). step is the 1-based step count. */
 int vp_adam_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                 float eps, int step, float grad_scale, vp_stream stream);
+/* The same update for a weight matrix p[R][Cn] whose gradient is a sum of K outer products, g = grad_scale * A^T B (A [K][R] =
+ * the output gradients, Bm [K][Cn] = the inputs of a Linear layer, models/networks.py:22,79): the gradient is contracted inside the
+ * update and never written.  Replaces the weight-gradient GEMM + vp_adam_f32 on that slice (encoder.fc.0: 134 MB not written
+ * and not re-read per step).  R, Cn multiples of 4. */
+int vp_adam_outer_f32(float* p, float* m, float* v, const float* A, const float* Bm, int K, int R, int Cn, float lr, float beta1,
+                      float beta2, float eps, int step, float grad_scale, vp_stream stream);
 /* torch.optim.RMSprop semantics (alpha, eps; no momentum, not centered) */
 int vp_rmsprop_f32(float* p, const float* g, float* sq, size_t n, float lr, float alpha, float eps,
                    float grad_scale, vp_stream stream);

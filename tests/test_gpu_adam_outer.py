@@ -1,0 +1,70 @@
+"""vp_adam_outer_f32: Adam on a weight matrix whose gradient is A^T B, contracted inside the update (the encoder's first dense layer in
+FusedVAEStep.step() on one rank).  Checked against torch.optim.Adam fed the materialised gradient, and end to end: the fused step
+with and without it must train the same parameters."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("K,R,Cn", [(32, 1024, 4096), (4, 36, 1028), (7, 16, 8)])
+def test_kernel_against_torch_adam(K, R, Cn):
+    from vae_play_amd import ops
+    g = torch.Generator().manual_seed(K + R + Cn)
+    A = torch.randn(K, R, generator=g).to(DEV)
+    Bm = torch.randn(K, Cn, generator=g).to(DEV)
+    p0 = (torch.randn(R, Cn, generator=g) * 0.1).to(DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    scale = 0.25
+    for step in range(1, 4):
+        ref.grad = (A.double().t() @ Bm.double()).float() * scale
+        opt.step()
+        ops.adam_outer_step(p, m, v, A, Bm, 1e-3, 0.9, 0.999, 1e-8, step, scale)
+        A, Bm = A * 0.7 + 0.1, Bm * 1.1 - 0.05          # new factors every step
+    st = opt.state[ref]
+    assert (p - ref.data).abs().max().item() <= 2e-6
+    assert (m - st["exp_avg"]).abs().max().item() <= 1e-5 * st["exp_avg"].abs().max().item()
+    assert (v - st["exp_avg_sq"]).abs().max().item() <= 5e-5 * st["exp_avg_sq"].abs().max().item()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_fused_step_with_and_without_the_factored_update(precision):
+    from tests.test_gpu_engine import build
+    from oracle import ref_cpu as O
+    C, S, z, B = 3, 32, 16, 8
+    x, eps = O.synthetic_batch(B, C, S, z)
+    xd, epsd = x.to(DEV), eps.to(DEV)
+    out = {}
+    old = os.environ.get("VP_ADAM_OUTER")
+    try:
+        for mode in ("1", "0"):
+            os.environ["VP_ADAM_OUTER"] = mode
+            vae, opt, fused, p0, L = build(C, S, z, B, precision=precision)
+            fcw = vae.encoder.fc[0].weight
+            fcw.grad.fill_(float("nan"))
+            for _ in range(3):
+                loss, _, _ = fused.step(xd, epsd)
+            torch.cuda.synchronize()
+            # the factored update never writes (or reads) the materialised gradient
+            assert torch.isnan(fcw.grad).all() == (mode == "1")
+            out[mode] = ({n: q.detach().clone() for n, q in vae.named_parameters()}, loss.item(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+    finally:
+        if old is None:
+            os.environ.pop("VP_ADAM_OUTER", None)
+        else:
+            os.environ["VP_ADAM_OUTER"] = old
+    a, b = out["1"], out["0"]
+    assert abs(a[1] - b[1]) <= 1e-6 * abs(b[1])
+    for n in a[0]:
+        d = (a[0][n] - b[0][n]).abs()
+        # three Adam steps of 1e-4: an element whose gradient is within rounding of zero may step the other way, and from the
+        # second step on the two runs see weights that differ by that rounding
+        assert (d > 2e-5).double().mean().item() <= 2e-3, n
+        assert d.max().item() <= 6.5e-4, n
+    assert (a[2] - b[2]).abs().max().item() <= 1e-5 * b[2].abs().max().item()
+    assert (a[3] - b[3]).abs().max().item() <= 1e-5 * b[3].abs().max().item()

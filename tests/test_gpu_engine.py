@@ -59,13 +59,14 @@ def test_fused_step_against_reference_golden(name, precision):
                 # The batch-4 fixtures amplify even fp32 rounding-ORDER noise the same way (BatchNorm1d over 4 samples):
                 # two dense kernels that are both 2e-7 from the fp64 product (tools/skinny_accuracy.py) moved
                 # encoder.l_var.bias from 4.8e-4 to 1.7e-3, so exact-fp32 mode keeps the 1e-3 bar at batch 32 only.
-                # f16x2 (declared tolerance: outputs 1e-3; ~2e-4 of contraction noise per layer): gradient norms to 2e-2, the
-                # per-tensor accuracy claim is tests/test_gpu_grad_accuracy.py's (fp64 oracle, same ReLU masks).
-                budget = 2e-2 if precision == "f16x2" else (tol if (precision == "f32" and B >= 32) else 5e-3)
+                # f16x2 (forward on three fp16 products, backward on two: ~2e-4 of contraction noise per backward layer) is held
+                # to bf16x3's budgets (measured worst gradient norm 9.4e-4); its per-tensor accuracy claim is
+                # tests/test_gpu_grad_accuracy.py's (fp64 oracle, same ReLU masks).
+                budget = tol if (precision == "f32" and B >= 32) else 5e-3
                 assert gerr <= budget, f"grad l2 {n}: {gerr:.2e} > {budget:.0e}"
                 idx = O.sample_indices(gr.numel())
                 d = (gr.flatten()[idx].double() - t(g[f"grad_samples/{n}"])).abs().max().item()
-                sample_tol = {"f32": tol, "bf16x3": 5e-3, "f16x2": 2e-2}[precision]
+                sample_tol = {"f32": tol, "bf16x3": 5e-3, "f16x2": 5e-3}[precision]
                 assert d <= sample_tol * 30 * max(l2 / gr.numel() ** 0.5, 1e-12), f"grad samples {n}"
             sd = vae.state_dict()
             for k in g:
@@ -77,7 +78,7 @@ def test_fused_step_against_reference_golden(name, precision):
             l2 = g[f"param{step}_l2/{n}"][0]
             pv = params[n].detach().cpu().double()
             upd = 1e-4 * step * pv.numel() ** 0.5
-            slack = {"f32": 0.02, "bf16x3": 0.06, "f16x2": 0.15}[precision]
+            slack = {"f32": 0.02, "bf16x3": 0.06, "f16x2": 0.06}[precision]
             assert abs(pv.pow(2).sum().sqrt().item() - l2) <= 1e-5 * l2 + slack * upd, f"param l2 step {step} {n}"
     fused.sync_counters()
     assert int(vae.encoder.conv[0].bn.num_batches_tracked) == steps

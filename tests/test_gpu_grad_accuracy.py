@@ -31,9 +31,9 @@ from tests.util import record
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 _CACHE = {}
-U_MODE = {"f32": 2.0 ** -20, "bf16x3": 2.0 ** -17, "f16x2": 2.0 ** -12}
-OUT_TOL = {"f32": 2e-5, "bf16x3": 1e-4, "f16x2": 1e-3}         # f16x2: the DECLARED tolerance of that mode (BASELINE's output bar)
-GRAD_FLOOR = {"f32": 1e-5, "bf16x3": 2e-4, "f16x2": 3e-3}      # gradient error given the same ReLU masks
+U_MODE = {"f32": 2.0 ** -20, "bf16x3": 2.0 ** -17, "f16x2": 2.0 ** -17}
+OUT_TOL = {"f32": 2e-5, "bf16x3": 1e-4, "f16x2": 1e-4}         # f16x2 runs its forward layers on three fp16 products
+GRAD_FLOOR = {"f32": 1e-5, "bf16x3": 2e-4, "f16x2": 1.5e-3}    # gradient error given the same ReLU masks (f16x2: DECLARED; measured 6.7e-4)
 
 
 def _rel(a, b):
@@ -133,7 +133,7 @@ def test_step_gradients_against_fp64_oracle(C, S, z, B, precision):
                             ("x_tilde", fused.x_tilde, o64["x_tilde"])):
         e = record(f"{precision}/out/{name}", _rel(ours, ref))
         assert e <= OUT_TOL[precision], f"{name}: {e:.2e}"
-    assert abs(loss.item() - o64["loss"].item()) <= (2e-4 if precision == "f16x2" else 2e-5) * abs(o64["loss"].item())
+    assert abs(loss.item() - o64["loss"].item()) <= 2e-5 * abs(o64["loss"].item())
     # ReLU masks: how many units did rounding put on the other side of zero?
     mh = _hip_masks(fused, B, S, L)
     assert [m.shape for m in mh] == [m.shape for m in m64]

@@ -130,7 +130,7 @@ def _worker_gpu(rank, port, out_dir, precision="f32", factored=1, overlap=True):
     vae.to("cuda").train()
     opt = optim.Adam(vae.parameters(), lr=1e-4)
     fused = engine.FusedVAEStep(vae, opt, hi - lo, S, C, precision=precision)
-    if precision == "bf16x3":
+    if precision != "f32":
         # the side-stream schedule and the fourth ("encoder tail") bucket that is reduced from the side stream exist
         assert fused._n_side_events > 0 and getattr(fused, "_bwd_b_enc_tail", None) is not None
     assert abs(opt.grad_scale - 1.0 / WORLD) < 1e-12
@@ -158,7 +158,7 @@ def _worker_gpu(rank, port, out_dir, precision="f32", factored=1, overlap=True):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision,factored,overlap", [("f32", 1, True), ("bf16x3", 1, True), ("bf16x3", 0, True), ("f32", 0, False),
-                                                        ("bf16x3", 1, False)])
+                                                        ("bf16x3", 1, False), ("f16x2", 1, True)])
 def test_dp_two_ranks_on_one_gpu_matches_oracle_definition(precision, factored, overlap):
     """Both exchange forms (factored fc.0 exchange / plain bucketed all-reduce), the single all-reduce (overlap=False), and both
     arithmetic modes: the split-bf16 plan adds the side-stream weight gradients and the encoder-tail bucket that is reduced from

@@ -213,9 +213,11 @@ using namespace vp;
 // XCD-aware tile order (igemm16.h): valid when the row-tile count is a multiple of 8 and there are >= 2 column tiles
 static int xcd_map_for(long M, long N, int gz) {
   const char* e = getenv("VP_XCD_MAP");
-  if (e && atoi(e) == 0) return 0;
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0) return 0;
   const Tile16 t = choose_tile16(M, N, gz);
   const long gx = (M + t.bm - 1) / t.bm, gy = (N + t.bn - 1) / t.bn;
+  if (mode == 2) return (gx % 8 == 0 && gx >= 16) ? 2 : 0;      // band order (igemm16.h): any column-tile / z count
   return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
 }
 

@@ -538,6 +538,66 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Adam update of a weight matrix p[R][Cn] whose gradient is a sum of K outer products, g = grad_scale * A^T B with A [K][R] and
+// B [K][Cn] (a Linear layer's weight gradient: A = the output gradients, B = the inputs of the K samples).  The gradient is
+// contracted in registers and consumed at once: for the encoder's first dense layer (1024 x 32768, 63 % of the model's parameters,
+// K = 32 images) that saves writing and re-reading a 134-MB gradient matrix per step.  One workgroup = 16 rows x 1024 columns,
+// one thread = 16 rows x 4 columns (64 accumulators); per k it loads one 16-B quad of B and 16 wave-uniform values of A.
+template <int AO_TI>
+__global__ void __launch_bounds__(256) adam_outer_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                         const float* __restrict__ A, const float* __restrict__ Bm, int K, int R, int Cn,
+                                                         float one_minus_b1, float b2, float one_minus_b2, float eps, float step_size,
+                                                         float bc2_sqrt, float grad_scale) {
+  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int i0 = blockIdx.y * AO_TI;
+  if (j >= Cn) return;
+  float acc[AO_TI][4];
+#pragma unroll
+  for (int i = 0; i < AO_TI; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[i][c] = 0.f;
+  const bool full = i0 + AO_TI <= R;
+  for (int k = 0; k < K; ++k) {
+    const vp_f32x4 b4 = *reinterpret_cast<const vp_f32x4*>(Bm + (size_t)k * Cn + j);
+    const float* ak = A + (size_t)k * R + i0;
+    float a[AO_TI];
+    if (full) {
+#pragma unroll
+      for (int q = 0; q < AO_TI / 4; ++q) {
+        const vp_f32x4 t = *reinterpret_cast<const vp_f32x4*>(ak + 4 * q);
+        a[4 * q] = t[0]; a[4 * q + 1] = t[1]; a[4 * q + 2] = t[2]; a[4 * q + 3] = t[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AO_TI; ++i) a[i] = i0 + i < R ? ak[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < AO_TI; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[i][c] = fmaf(a[i], b4[c], acc[i][c]);
+  }
+#pragma unroll      // (fully: a runtime row index would send the accumulators to scratch)
+  for (int i = 0; i < AO_TI; ++i) {
+    if (i0 + i >= R) continue;
+    const size_t o = (size_t)(i0 + i) * Cn + j;
+    vp_f32x4 pv = *reinterpret_cast<vp_f32x4*>(p + o);
+    vp_f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(m + o));
+    vp_f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(v + o));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float gr = acc[i][c] * grad_scale;
+      mv[c] = mv[c] + one_minus_b1 * (gr - mv[c]);
+      vv[c] = vv[c] * b2 + one_minus_b2 * gr * gr;
+      const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
+      pv[c] = pv[c] - step_size * (mv[c] / denom);
+    }
+    *reinterpret_cast<vp_f32x4*>(p + o) = pv;
+    __builtin_nontemporal_store(mv, reinterpret_cast<vp_f32x4*>(m + o));
+    __builtin_nontemporal_store(vv, reinterpret_cast<vp_f32x4*>(v + o));
+  }
+}
+
+
 // torch.optim.RMSprop: sq = alpha*sq + (1-alpha)*g*g; p -= lr * g / (sqrt(sq) + eps)
 __global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
                                                       size_t n, float lr, float alpha, float one_minus_alpha, float eps,
@@ -799,6 +859,26 @@ int vp_adam_f32(float* p, const float* g, float* m, float* v, size_t n, float lr
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, cap)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                      1.f - beta1, beta2, 1.f - beta2, eps, step_size, bc2_sqrt, grad_scale);
   return check_launch("vp_adam_f32");
+}
+
+int vp_adam_outer_f32(float* p, float* m, float* v, const float* A, const float* Bm, int K, int R, int Cn, float lr, float beta1,
+                      float beta2, float eps, int step, float grad_scale, vp_stream stream) {
+  VP_REQUIRE(p && m && v && A && Bm && K > 0 && R > 0 && Cn > 0 && step >= 1, "vp_adam_outer_f32: bad arguments");
+  VP_REQUIRE(Cn % 4 == 0 && R % 4 == 0, "vp_adam_outer_f32: R and Cn must be multiples of 4");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  static const int ti = [] { const char* e = getenv("VP_ADAM_OUTER_ROWS"); return e ? atoi(e) : 16; }();      // A/B knob: 8 | 16
+  const int TI = ti == 8 ? 8 : 16;
+  const dim3 grid((unsigned)((Cn / 4 + 255) / 256), (unsigned)((R + TI - 1) / TI));
+  VP_REQUIRE(grid.y <= 65535, "vp_adam_outer_f32: too many rows");
+  if (TI == 8)
+    hipLaunchKernelGGL(adam_outer_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, p, m, v, A, Bm, K, R, Cn, 1.f - beta1, beta2, 1.f - beta2,
+                       eps, step_size, bc2_sqrt, grad_scale);
+  else
+    hipLaunchKernelGGL(adam_outer_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, p, m, v, A, Bm, K, R, Cn, 1.f - beta1, beta2, 1.f - beta2,
+                       eps, step_size, bc2_sqrt, grad_scale);
+  return check_launch("vp_adam_outer_f32");
 }
 
 int vp_rmsprop_f32(float* p, const float* g, float* sq, size_t n, float lr, float alpha, float eps, float grad_scale,

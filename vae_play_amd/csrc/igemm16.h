@@ -524,21 +524,31 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  int tx = blockIdx.x, ty = blockIdx.y;
+  int tx = blockIdx.x, ty = blockIdx.y, tz = blockIdx.z;
   if constexpr (!P::A_KM) {
-    if (p.xcd_map) {
+    if (p.xcd_map == 1) {
       // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs in launch order; give the gridDim.y
       // column tiles that read the same activation rows hardware ids that are equal modulo 8 (same XCD, same L2)
       const int hid = blockIdx.x + gridDim.x * blockIdx.y;
       const int r = hid & 7, q = hid >> 3;
       tx = r + 8 * (q / (int)gridDim.y);
       ty = q % (int)gridDim.y;
+    } else if (p.xcd_map == 2) {
+      // band order: XCD r owns the contiguous band of row tiles [r * gx/8, (r+1) * gx/8) and walks it in order, and every
+      // (column tile, z slice) of one row tile -- the phases of a transposed convolution and the halves of a split K read the
+      // SAME activation rows -- runs back to back on that XCD: neighbouring row tiles share their halo rows in one L2
+      const int hid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int r = hid & 7, q = hid >> 3, inner = (int)(gridDim.y * gridDim.z);
+      const int yz = q % inner;
+      tx = r * (int)(gridDim.x >> 3) + q / inner;
+      ty = yz % (int)gridDim.y;
+      tz = yz / (int)gridDim.y;
     }
   }
   const int m0 = tx * BM, n0 = ty * BN;
 
   typename P::ZCtx z;
-  p.z_setup(blockIdx.z, z);
+  p.z_setup(tz, z);
 
   // staging map.  MK: chunk = (row = tid/(2*KC) + RPP*i, sub = tid%(2*KC) -> plane = sub/KC, k8 = sub%KC)
   //               KM: chunk = (krow, col8, plane) with V = BR/8 chunks per k-row and plane
@@ -741,10 +751,10 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 
   if constexpr (P::HAS_STAT) {
     if (p.stat)      // (workgroup-uniform) every wave is past its last LDS read: the loop ends with a barrier
-      epilogue_stats32<BM, BN, WM, WN, TM, TN>(p.stat, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, p.M, p.N, acc, lds, m0, n0,
+      epilogue_stats32<BM, BN, WM, WN, TM, TN>(p.stat, (int)(gridDim.x * gridDim.z), (int)(tz * gridDim.x) + tx, p.M, p.N, acc, lds, m0, n0,
                                                wm, wn, li, lh, tid);
     if (p.bsum)
-      epilogue_bnbwd32<P, BM, BN, WM, WN, TM, TN>(p, z, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, acc, lds, m0, n0,
+      epilogue_bnbwd32<P, BM, BN, WM, WN, TM, TN>(p, z, (int)(gridDim.x * gridDim.z), (int)(tz * gridDim.x) + tx, acc, lds, m0, n0,
                                                   wm, wn, li, lh, tid);
   }
 #pragma unroll

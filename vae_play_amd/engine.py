@@ -94,6 +94,10 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+def _noop():
+    return None
+
+
 class FusedVAEStep:
     """forward + loss + backward (+ all-reduce + optimiser) for a ``networks.VAE``.
 
@@ -826,11 +830,26 @@ class FusedVAEStep:
             for w in works:
                 if w is not None:
                     w.wait()
+        elif self.world == 1 and self._outer_adam():
+            # one rank: encoder.fc.0's weight gradient (134 MB at config 3) is contracted from its two factors inside the Adam
+            # kernel instead of being written by a GEMM and read back by the update; fc.0.weight.grad is NOT written by step()
+            # (forward_backward() alone materialises every gradient).
+            out = self.forward_backward(x, eps, timers, on_fc_wgrad=_noop)
+            self.opt.step(outer=True)
+            return out
         else:
             out = self.forward_backward(x, eps, timers)
             parallel.allreduce_flat_grads(self.opt.flat_grad, self.group)
         self.opt.step()
         return out
+
+    def _outer_adam(self) -> bool:
+        if os.environ.get("VP_ADAM_OUTER", "1") == "0" or not hasattr(self.opt, "set_outer_grad"):
+            return False
+        if getattr(self.opt, "_outer", None) is None:
+            dh, flat, fcw, F0 = self._fc_factors
+            self.opt.set_outer_grad(fcw, dh.view(self.B, 1024), flat.view(self.B, F0))
+        return True
 
     def capture(self, warmup: int = 2):
         """Capture forward+backward into a hipGraph (torch.cuda.CUDAGraph) and replay it from then on."""

@@ -407,6 +407,14 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step: int, grad_scale: float = 
               int(step), float(grad_scale), _stream())
 
 
+def adam_outer_step(p2d, m2d, v2d, A, Bm, lr, beta1, beta2, eps, step: int, grad_scale: float = 1.0):
+    """Adam on p2d [R][Cn] with the gradient grad_scale * A^T Bm (A [K][R], Bm [K][Cn]) contracted inside the update."""
+    R, Cn = p2d.shape
+    K = A.shape[0]
+    assert A.shape == (K, R) and Bm.shape == (K, Cn) and A.is_contiguous() and Bm.is_contiguous() and p2d.is_contiguous()
+    _lib.call("vp_adam_outer_f32", _p(p2d), _p(m2d), _p(v2d), _p(A), _p(Bm), K, R, Cn, lr, beta1, beta2, eps, step, grad_scale, _stream())
+
+
 def rmsprop_step(p, g, sq, lr, alpha, eps, grad_scale: float = 1.0):
     _lib.call("vp_rmsprop_f32", _p(p), _p(g), _p(sq), p.numel(), float(lr), float(alpha), float(eps), float(grad_scale), _stream())
 

@@ -172,14 +172,33 @@ class Adam(_FlatOptimizer):
             ops.adam_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
                           self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale)
 
+    def set_outer_grad(self, param, A: torch.Tensor, Bm: torch.Tensor) -> None:
+        """Declare that ``param`` (a [R][Cn] weight of this arena) has the gradient A^T Bm (A [K][R], Bm [K][Cn], static
+        buffers): ``step(outer=True)`` then contracts it inside the update (ops.adam_outer_step) and does not read
+        ``param.grad``."""
+        a = self.arena
+        off = a.offsets[[id(q) for q in a.params].index(id(param))]
+        R, Cn = param.shape
+        assert A.shape[1] == R and Bm.shape[1] == Cn and A.shape[0] == Bm.shape[0]
+        self._outer = (off, (param.numel() + 63) // 64 * 64, R, Cn, A, Bm)
+
     @torch.no_grad()
-    def step(self) -> None:
+    def step(self, outer: bool = False) -> None:
         self.step_count += 1
         a = self.arena
         if a.numel:
             a.gather_grads()
-            ops.adam_step(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                          self.eps, self.step_count, self.grad_scale)
+            if outer and getattr(self, "_outer", None) is not None:
+                off, span, R, Cn, A, Bm = self._outer
+                n = R * Cn
+                self.step_range(0, off)
+                ops.adam_outer_step(a.flat_param[off:off + n].view(R, Cn), self.exp_avg[off:off + n].view(R, Cn),
+                                    self.exp_avg_sq[off:off + n].view(R, Cn), A, Bm, self.lr, self.betas[0], self.betas[1], self.eps,
+                                    self.step_count, self.grad_scale)
+                self.step_range(off + span, a.flat_param.numel())
+            else:
+                ops.adam_step(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
+                              self.eps, self.step_count, self.grad_scale)
         for p, m, v, cnt in self._fstate:
             if p.grad is None:
                 continue
