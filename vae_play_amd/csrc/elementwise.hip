@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) adam_outer_kernel(float* __restrict__ p, 
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[i][c] = 0.f;
   const bool full = i0 + AO_TI <= R;
-  for (int k = 0; k < K; ++k) {
+  auto kstep = [&](int k) {
     const vp_f32x4 b4 = *reinterpret_cast<const vp_f32x4*>(Bm + (size_t)k * Cn + j);
     const float* ak = A + (size_t)k * R + i0;
     float a[AO_TI];
@@ -575,25 +575,45 @@ __global__ void __launch_bounds__(256) adam_outer_kernel(float* __restrict__ p, 
     for (int i = 0; i < AO_TI; ++i)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[i][c] = fmaf(a[i], b4[c], acc[i][c]);
+  };
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {      // four k per trip: their loads are issued together
+    kstep(k); kstep(k + 1); kstep(k + 2); kstep(k + 3);
   }
-#pragma unroll      // (fully: a runtime row index would send the accumulators to scratch)
-  for (int i = 0; i < AO_TI; ++i) {
-    if (i0 + i >= R) continue;
-    const size_t o = (size_t)(i0 + i) * Cn + j;
-    vp_f32x4 pv = *reinterpret_cast<vp_f32x4*>(p + o);
-    vp_f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(m + o));
-    vp_f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(v + o));
+  for (; k < K; ++k) kstep(k);
+  auto upd = [&](vp_f32x4& pv, vp_f32x4& mv, vp_f32x4& vv, const float (&g4)[4]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float gr = acc[i][c] * grad_scale;
+      const float gr = g4[c] * grad_scale;
       mv[c] = mv[c] + one_minus_b1 * (gr - mv[c]);
       vv[c] = vv[c] * b2 + one_minus_b2 * gr * gr;
       const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
       pv[c] = pv[c] - step_size * (mv[c] / denom);
     }
-    *reinterpret_cast<vp_f32x4*>(p + o) = pv;
-    __builtin_nontemporal_store(mv, reinterpret_cast<vp_f32x4*>(m + o));
-    __builtin_nontemporal_store(vv, reinterpret_cast<vp_f32x4*>(v + o));
+  };
+  // rows in groups of four: 12 independent 16-B loads in flight before the first use (every row index is a compile-time
+  // constant: a runtime index would send the accumulators to scratch)
+#pragma unroll
+  for (int i4 = 0; i4 < AO_TI; i4 += 4) {
+    vp_f32x4 pv[4], mv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = i0 + i4 + u;
+      const size_t o = (size_t)(r < R ? r : R - 1) * Cn + j;         // (rows past the end: clamped load, no store)
+      pv[u] = *reinterpret_cast<vp_f32x4*>(p + o);
+      mv[u] = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(m + o));
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<vp_f32x4*>(v + o));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = i0 + i4 + u;
+      if (r >= R) continue;
+      const size_t o = (size_t)r * Cn + j;
+      upd(pv[u], mv[u], vv[u], acc[i4 + u]);
+      *reinterpret_cast<vp_f32x4*>(p + o) = pv[u];
+      __builtin_nontemporal_store(mv[u], reinterpret_cast<vp_f32x4*>(m + o));
+      __builtin_nontemporal_store(vv[u], reinterpret_cast<vp_f32x4*>(v + o));
+    }
   }
 }
 
@@ -868,7 +888,7 @@ int vp_adam_outer_f32(float* p, float* m, float* v, const float* A, const float*
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  static const int ti = [] { const char* e = getenv("VP_ADAM_OUTER_ROWS"); return e ? atoi(e) : 16; }();      // A/B knob: 8 | 16
+  static const int ti = [] { const char* e = getenv("VP_ADAM_OUTER_ROWS"); return e ? atoi(e) : 8; }();      // A/B knob: 8 (142 us on the 1024 x 32768 layer) | 16 (150 us)
   const int TI = ti == 8 ? 8 : 16;
   const dim3 grid((unsigned)((Cn / 4 + 255) / 256), (unsigned)((R + TI - 1) / TI));
   VP_REQUIRE(grid.y <= 65535, "vp_adam_outer_f32: too many rows");
