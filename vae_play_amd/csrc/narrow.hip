@@ -393,23 +393,26 @@ __global__ void __launch_bounds__(512, 2) conv5s1_tapn_kernel(const float* __res
     }
   }
 
+  // patch row tile t of output tile `tile`: 32 pixels x 64 channels, one 128-B half line per lane
+  auto load_tile = [&](int tile, int t, vp_f32x4 (&raw)[8]) {
+    const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+    const int h0 = (rem / tiles_x) * T, w0 = (rem % tiles_x) * T;
+    const int pi = 32 * t + li;
+    const int py = pi / HALO, px = pi - py * HALO;
+    const int gh = h0 + py - 2, gw = w0 + px - 2;
+    const bool ok = pi < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    const float* q = in + ((size_t)(b * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * C + 32 * lh;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) raw[v] = ok ? ld4(q + 4 * v) : zero4();
+  };
+  vp_f32x4 cur[8], nxt[8];
+  if ((int)blockIdx.x < ntiles && wave < MT) load_tile(blockIdx.x, wave, cur);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
     const int h0 = (rem / tiles_x) * T, w0 = (rem % tiles_x) * T;
-    auto load_tile = [&](int t, vp_f32x4 (&raw)[8]) {
-      const int pi = 32 * t + li;
-      const int py = pi / HALO, px = pi - py * HALO;
-      const int gh = h0 + py - 2, gw = w0 + px - 2;
-      const bool ok = pi < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W;
-      const float* q = in + ((size_t)(b * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * C + 32 * lh;
-#pragma unroll
-      for (int v = 0; v < 8; ++v) raw[v] = ok ? ld4(q + 4 * v) : zero4();
-    };
-    vp_f32x4 cur[8], nxt[8];
-    if (wave < MT) load_tile(wave, cur);
     for (int t = wave; t < MT; t += NWAVE) {
       const bool more = t + NWAVE < MT;
-      if (more) load_tile(t + NWAVE, nxt);
+      if (more) load_tile(tile, t + NWAVE, nxt);
       f32x16_e acc[NT];
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt)
@@ -438,6 +441,10 @@ __global__ void __launch_bounds__(512, 2) conv5s1_tapn_kernel(const float* __res
         for (int v = 0; v < 8; ++v) cur[v] = nxt[v];
       }
     }
+    // the first patch rows of the workgroup's NEXT tile are requested before the shifted sum: their latency hides under it
+    // (one workgroup per CU -- P takes 155 KB of LDS -- so nothing else would fill that gap)
+    const int ntile = tile + (int)gridDim.x;
+    if (ntile < ntiles && wave < MT) load_tile(ntile, wave, cur);
     __syncthreads();
     if (tid < T * T) {
       const int tx = tid % T, ty = tid / T;

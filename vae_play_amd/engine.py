@@ -183,6 +183,7 @@ class FusedVAEStep:
 
         # fp16 plans: forward layers contract with three products (outputs keep the bf16x3 tolerance), backward layers with two
         FWD_PRODUCTS = int(os.environ.get("VP_F16_FWD_PRODUCTS", "3"))     # A/B knob (2: the forward also on two MFMAs)
+        DEC_FWD_PRODUCTS = int(os.environ.get("VP_F16_DEC_FWD_PRODUCTS", str(FWD_PRODUCTS)))   # decoder forward only
 
         def add_gather(plan, a_s, w_s, bias, out, geom, act, alpha=1.0, products=2, **kw):
             if x2:
@@ -246,13 +247,13 @@ class FusedVAEStep:
                 nst = query(family, *qgeom) if fuse_stats else 0
                 if nst:
                     st = self._ws(f"{tag}.statws", nst)
-                    fwd.add(name.replace("_bf16x3", "_stats_f16" if x2 else "_stats_bf16x3"), *lead, *geom, *((FWD_PRODUCTS,) if x2 else ()),
+                    fwd.add(name.replace("_bf16x3", "_stats_f16" if x2 else "_stats_bf16x3"), *lead, *geom, *(((FWD_PRODUCTS if family == 0 else DEC_FWD_PRODUCTS),) if x2 else ()),
                             eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean), P(bn_mod.running_var), P(st), st.numel() * 4,
                             flops=fl, tag=ctag)
                     fused = True
                 else:
                     extra = (None,) if family == 0 else ()
-                    tail = ((_ACT_NONE,) if family == 0 else ()) + ((FWD_PRODUCTS, 1.0) if x2 else ())
+                    tail = ((_ACT_NONE,) if family == 0 else ()) + (((FWD_PRODUCTS if family == 0 else DEC_FWD_PRODUCTS), 1.0) if x2 else ())
                     fwd.add(name.replace("_bf16x3", "_f16") if x2 else name, lead[0], lead[1], *extra, lead[2], *geom, *tail, flops=fl, tag=ctag)
             if not fused:
                 fwd.add("vp_bn_stats_f32", P(x_buf), R, Cn, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
