@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-end measurement set (run on the GPU box through gpurun; outputs under gpurun_out/prof, copied into profiles/ by hand):
+#   bench line, rocprofv3 kernel tables (serial / concurrent schedule, bf16x3 and f16x2), MFMA-busy and HBM-traffic PMC passes.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+cd $R
+B="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants"
+P="bench.py --steps 2 --warmup 1 --no-settle --no-cpu-baseline --no-variants"
+timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
+echo "bench done"
+VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_serial -o t -- python3 $B > $O/ks_serial.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_conc -o t -- python3 $B > $O/ks_conc.log 2>&1 || exit 1
+VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_x2_serial -o t -- python3 $B --precision f16x2 > $O/ks_x2_serial.log 2>&1 || exit 1
+echo "kernel stats done"
+VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o t -- python3 $P > $O/mfma.log 2>&1 || exit 1
+VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma_x2 -o t -- python3 $P --precision f16x2 > $O/mfma_x2.log 2>&1 || exit 1
+echo "mfma done"
+VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o t -- python3 $P > $O/fetch.log 2>&1 || exit 1
+VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o t -- python3 $P > $O/write.log 2>&1 || exit 1
+VP_SIDE_WGRAD=0 VP_XCD_MAP=2 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_band -o t -- python3 $P > $O/fetch_band.log 2>&1 || exit 1
+echo "traffic done"
+find $O -name "*.csv" | head -40
+du -sh $O
