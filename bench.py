@@ -43,6 +43,18 @@ CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32
               "vp_conv5_scatter_stats_f16", "vp_conv_gather_f16", "vp_conv_wgrad_f16x2"}
 
 
+def mfma_products(name, tag):
+    """MFMAs issued per algorithmic product by the launch `name` (tag = its layer): 3 on bf16 pairs, 3 (forward layers) or 2
+    (backward layers) on fp16 pairs, 1 on the exact-fp32 kernels."""
+    if name.endswith("bf16x3"):
+        return 3
+    if name.endswith("_f16x2"):
+        return 2
+    if name.endswith("_f16"):
+        return 3 if (tag or "").endswith(".fwd") else 2
+    return 1
+
+
 def measured_traffic(api_name):
     """HBM bytes per launch of a conv family from the committed PMC passes (profiles/*_traffic.json, newest round);
     None when no measurement is on file for that kernel."""
@@ -217,10 +229,11 @@ def measure(fused, x, eps, steps, untimed, world, graph, overlap=True, tags_out=
         measured = "instrumented-pass-after-timed-region"
     fam = {}
     for name, tag, flops, e0, e1 in timers["events"]:
-        d = fam.setdefault(name.replace("_stats_", "_").replace("_bnbwd_", "_"), [0.0, 0.0, 0])
+        d = fam.setdefault(name.replace("_stats_", "_").replace("_bnbwd_", "_"), [0.0, 0.0, 0, 0.0])
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
+        d[3] += flops * mfma_products(name, tag)
     if tags_out:
         per = {}
         for name, tag, flops, e0, e1 in timers["events"]:
@@ -240,11 +253,10 @@ def roofline_of(m, steps, B, S, C, z):
     tot_t = sum(v[1] for v in fam.values())
     ach = fam[dom][0] / fam[dom][1] / 1e12
     is16 = dom.endswith("bf16x3") or dom.endswith("f16x2") or dom.endswith("_f16")
-    # the fp16 gather / scatter entry points carry forward (3 products) and backward (2 products) launches: priced at 2
-    per_product = 3 if dom.endswith("bf16x3") else (2 if is16 else 1)
+    per_product = fam[dom][3] / fam[dom][0]      # MFMAs per product, averaged over the family's launches (fp16: 3 forward, 2 backward)
     peak = PEAK_BF16_MFMA_TFLOPS if is16 else PEAK_FP32_MFMA_TFLOPS       # fp16 and bf16 MFMAs have the same dense peak
-    kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if per_product == 3
-             else "igemm16_kernel, 2 (backward) or 3 (forward) x v_mfma_f32_32x32x16_f16 per product" if per_product == 2
+    kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if dom.endswith("bf16x3")
+             else "igemm16_kernel, 2 (backward) or 3 (forward) x v_mfma_f32_32x32x16_f16 per product" if is16
              else "igemm_kernel, v_mfma_f32_32x32x2_f32")
     # the committed PMC passes were taken on the default workload only
     traffic, traffic_src = measured_traffic(dom) if (S, C, z, B) == (128, 3, 128, 32) else (None, None)
@@ -252,7 +264,7 @@ def roofline_of(m, steps, B, S, C, z):
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC)",
             "traffic_source": traffic_src,
-            "mfma_issue_frac": round(ach * per_product / peak, 4),
+            "mfma_issue_frac": round(ach * per_product / peak, 4), "mfma_per_product": round(per_product, 3),
             "launches": fam[dom][2], "avg_launch_ms": round(fam[dom][1] / fam[dom][2] * 1e3, 4),
             "all_conv_families_tflops": round(tot_f / tot_t / 1e12, 2),
             "conv_share_of_step_time": round(tot_t / m["n_inst"] / (m["elapsed"] / steps), 3),
