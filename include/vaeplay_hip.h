@@ -140,6 +140,11 @@ int vp_conv5_scatter_stats_bf16x3(const void* small_split, const void* w_p1_spli
                                   int B, int Hs, int Ws, int Csmall, int Cbig, int stride, float eps, float momentum,
                                   float* mean, float* rstd, float* running_mean, float* running_var,
                                   void* ws, size_t ws_bytes, vp_stream stream);
+/* Input gradient of the final conv (nn.Conv2d(64 -> C, k5, s1, p2), models/networks.py:100-103, autograd backward) for C = 1 | 3
+ * image channels: big_out[b,h,w,cf] = sum_{r,q,n} small[b, h-r+2, w-q+2, n] * w_ref[n][cf][r][q], fp32 NHWC operands, reference weight
+ * layout, split-bf16 arithmetic on the matrix cores with one kernel row of taps (5*C contiguous floats of `small`) per MFMA k-step. */
+int vp_conv5_smallin_dgrad_bf16x3(const float* small, const float* w_ref, float* big_out, int B, int H, int W, int Csmall, int Cbig,
+                                  vp_stream stream);
 /* Input-gradient convolution + the reduction pass of the BatchNorm backward it feeds (autograd of nn.BatchNorm2d + F.relu,
  * models/networks.py:28-29,44-45): the launch's output small_out / big_out is dy of a BatchNorm(+ReLU) layer whose convolution
  * output is bn_x (same layout); the epilogue emits per-workgroup {sum g, sum g*xhat}, g = dy * act'(gamma*xhat + beta), and one

@@ -60,3 +60,26 @@ def test_final_conv_weight_gradient_tapm_matches_torch(B, H, W, nout):
     dw2 = torch.empty_like(dw)
     _lib.call("vp_conv5_smallout_wgrad_bf16x3", ops._p(ud), ops._p(dld), ops._p(dw2), B, H, W, 64, nout, ops._p(ws), nbytes, ops._stream())
     assert torch.equal(dw, dw2), "slab reduction must be bit-reproducible"
+
+
+@pytest.mark.parametrize("B,H,W,nin", [(2, 16, 32, 3), (1, 24, 40, 3), (3, 33, 17, 1), (2, 128, 128, 3), (1, 256, 256, 1)])
+def test_final_conv_input_gradient_rowk_matches_torch(B, H, W, nin):
+    """csrc/edge.hip dgrad_rowk_kernel (one kernel row of taps per MFMA k-step) against torch's autograd input gradient of
+    Conv2d(64 -> C, k5, s1, p2) on the CPU (ragged sizes included: tiles are 8 x 32 pixels)."""
+    from vae_play_amd import _lib, ops
+    g = torch.Generator().manual_seed(13 + H + nin)
+    dl = (torch.rand(B, nin, H, W, generator=g) - 0.5) / B
+    w = (torch.rand(nin, 64, 5, 5, generator=g) - 0.5) * 0.1
+    u = torch.zeros(B, 64, H, W, requires_grad=True)
+    (F.conv2d(u, w, None, padding=2) * dl).sum().backward()
+    ref = u.grad
+    dld = ops.channels_last(dl.cuda())
+    out = torch.full((B, 64, H, W), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
+    _lib.call("vp_conv5_smallin_dgrad_bf16x3", ops._p(dld), ops._p(w.cuda()), ops._p(out), B, H, W, nin, 64, ops._stream())
+    assert torch.isfinite(out).all(), "every output element must be written"
+    assert_close(out.cpu(), ref, 3e-5, f"final conv input gradient rows-in-K {B}x{H}x{W}x{nin}")
+    for sl in ((..., 0, slice(None)), (..., H - 1, slice(None)), (..., slice(None), 0), (..., slice(None), W - 1)):
+        assert_close(out.cpu()[sl], ref[sl], 1e-4, "border")
+    # the exact-fp32 scatter kernel computes the same gradient
+    _, p1 = ops.pack_w5(w.cuda(), False, True)
+    assert_close(out.cpu(), ops.conv5_scatter(dld, p1, 1).cpu(), 3e-5, "rows-in-K vs exact-f32 kernel")

@@ -174,6 +174,127 @@ int tapm_wgrad_launch(const float* big_f32, const float* small_f32, float* dw_re
   return slab_reduce_launch(ws, dw_ref, g.Cs, g.Cb, nblk, s, kTaps);      // few outputs, many slabs: the deep reduction kernel
 }
 
+
+// ---- input gradient of the final conv: one kernel ROW of taps per MFMA k-step ("rows in K") ---------------------------------------
+//     du[b,h,w,cf] = sum_{r,q,n} dlogit[b, h-r+2, w-q+2, n] * W[n][cf][r][q]          (nn.Conv2d(64 -> C, k5, s1, p2) backward, C = 1 | 3)
+// The implicit GEMM on channel-padded planes (halo.hip: 3 -> 8 channels, K = 25*8 = 200) spends 2.7x the MFMAs the layer needs and
+// is MFMA-bound (61 us at B = 32, 128x128) where the layer's floor is writing its 134-MB fp32 result.  In the NHWC gradient image the
+// 5 taps of one kernel row are 5*C <= 15 CONTIGUOUS floats, (w-2 .. w+2) x C: they are one 16-deep MFMA k-step (k = 3*d + n, d = the
+// column offset, tap q = 4 - d; k >= 5*C is zero), so K = 5 rows x 16 = 80.
+//   * a workgroup (8 waves) owns 8 rows x 32 columns of output pixels; the 12 x 36 x C patch of dlogit is staged in LDS as fp32
+//     (zeros outside the image: no masks later), a wave takes one output row = one 32-pixel MFMA row tile;
+//   * A fragment of kernel row r: 8 consecutive fp32 of patch row (row + 4 - r), split to bf16 hi / lo in registers;
+//   * B fragments (5 rows x 64 output channels x 16 k, from the reference weight layout) are gathered and split once per workgroup
+//     and parked in LDS in fragment order; workgroups are persistent over the tile list, two per CU, and request the next tile's
+//     patch before the current tile's MFMAs and stores;
+//   * 30 MFMAs (5 k-steps x 2 column tiles x 3 products) per 32 pixels x 64 channels, then 8 KB of stores.
+template <int NIN>
+__global__ void __launch_bounds__(512, 2) dgrad_rowk_kernel(const float* __restrict__ dlogit, const float* __restrict__ w,
+                                                            float* __restrict__ out, int H, int W, int tiles_x, int tiles_per_img,
+                                                            int ntiles) {
+  constexpr int CF = 64, TR = 8, TC = 32, PR = TR + 4, PC = (TC + 4) * NIN + 8;     // patch: 12 rows x (36 pixels x NIN floats, + slack)
+  constexpr int KROW = 5 * NIN;                                                     // useful k per kernel row (<= 15)
+  __shared__ float patch[PR * PC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
+  typedef float f32x16_l __attribute__((ext_vector_type(16)));
+  __shared__ __attribute__((aligned(16))) bf16x8_l bfr[5 * 2 * 2 * 64];                                // weight fragments [r][jt][hi|lo][lane]
+  auto split8 = [](const float (&x)[8], bf16x8_l& h, bf16x8_l& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 hh = (__bf16)x[j];
+      h[j] = hh;
+      l[j] = (__bf16)(x[j] - (float)hh);
+    }
+  };
+  // B[r][cf][k]: k = NIN*d + n  <->  W[n][cf][r][4 - d]; a lane's fragment: cf = 32*jt + li, k = 8*lh + 0..7.  Gathered and split
+  // once per workgroup (wave r builds kernel row r) and parked in LDS in fragment order: registers stay free for two workgroups per CU
+  if (wave < 5) {
+    const int r = wave;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * lh + j, d = k / NIN, n = k - d * NIN;
+        x[j] = k < KROW ? w[(((size_t)n * CF + 32 * jt + li) * 5 + r) * 5 + (4 - d)] : 0.f;
+      }
+      bf16x8_l h8, l8;
+      split8(x, h8, l8);
+      bfr[((r * 2 + jt) * 2 + 0) * 64 + lane] = h8;
+      bfr[((r * 2 + jt) * 2 + 1) * 64 + lane] = l8;
+    }
+  }
+  // the patch of a tile: PR x (TC+4) x NIN floats, <= 3 per thread; the NEXT tile's values are requested before this tile's MFMAs and
+  // stores and parked in registers (one workgroup per CU: nothing else would hide that latency)
+  constexpr int NPE = PR * (TC + 4) * NIN, NPV = (NPE + 511) / 512;
+  float pv[NPV];
+  auto load_patch = [&](int tile) {
+    const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+    const int h0 = (rem / tiles_x) * TR, w0 = (rem % tiles_x) * TC;
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) {
+      const int i = tid + 512 * u;
+      const int pr = i / ((TC + 4) * NIN), e = i - pr * ((TC + 4) * NIN);
+      const int px = e / NIN, n = e - px * NIN;
+      const int h = h0 - 2 + pr, ww = w0 - 2 + px;
+      pv[u] = (i < NPE && h >= 0 && h < H && ww >= 0 && ww < W) ? dlogit[((size_t)(b * H + h) * W + ww) * NIN + n] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_patch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+    const int h0 = (rem / tiles_x) * TR, w0 = (rem % tiles_x) * TC;
+    __syncthreads();                       // the previous tile's fragment reads are done
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) {
+      const int i = tid + 512 * u;
+      if (i < NPE) { const int pr = i / ((TC + 4) * NIN); patch[pr * PC + (i - pr * ((TC + 4) * NIN))] = pv[u]; }
+    }
+    if (tid < PR * 8) patch[(tid >> 3) * PC + (TC + 4) * NIN + (tid & 7)] = 0.f;      // the slack a k >= KROW read may touch
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_patch(tile + (int)gridDim.x);
+    f32x16_l acc[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      // output pixel (row = wave, column li): gradient row h - r + 2 = patch row wave + 4 - r, columns w-2 .. w+2 = patch pixel li ..
+      const float* q = &patch[(wave + 4 - r) * PC + li * NIN + 8 * lh];
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = (8 * lh + j < KROW) ? q[j] : 0.f;
+      bf16x8_l ah, al;
+      split8(x, ah, al);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        const bf16x8_l bh = bfr[((r * 2 + jt) * 2 + 0) * 64 + lane], bl = bfr[((r * 2 + jt) * 2 + 1) * 64 + lane];
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[jt], 0, 0, 0);
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[jt], 0, 0, 0);
+        acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[jt], 0, 0, 0);
+      }
+    }
+    const int h = h0 + wave;
+    if (h < H) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ww = w0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (ww < W) out[((size_t)(b * H + h) * W + ww) * CF + 32 * jt + li] = acc[jt][e];
+        }
+    }
+  }
+}
+
+bool rowk_dgrad_applicable(int B, int H, int W, int Cbig, int Csmall) {
+  static const bool on = [] { const char* e = getenv("VP_ROWK"); return !e || atoi(e) != 0; }();
+  return on && B > 0 && H > 0 && W > 0 && Cbig == 64 && (Csmall == 1 || Csmall == 3);
+}
+
 }  // namespace vp
 
 using namespace vp;
@@ -193,6 +314,21 @@ int vp_conv5_smallout_wgrad_bf16x3(const float* big, const float* small, float* 
   VP_REQUIRE(tapm_wgrad_applicable(g), "vp_conv5_smallout_wgrad_bf16x3: needs 64 input channels, 1 or 3 outputs, width a multiple of 64, height of 16");
   if (ws_bytes < tapm_wgrad_ws_floats(g) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_smallout_wgrad_bf16x3: workspace too small");
   return tapm_wgrad_launch(big, small, dw_ref, g, (float*)ws, (hipStream_t)stream);
+}
+
+int vp_conv5_smallin_dgrad_bf16x3(const float* small, const float* w_ref, float* big_out, int B, int H, int W, int Csmall, int Cbig,
+                                  vp_stream stream) {
+  VP_REQUIRE(small && w_ref && big_out, "vp_conv5_smallin_dgrad_bf16x3: null pointer");
+  VP_REQUIRE(rowk_dgrad_applicable(B, H, W, Cbig, Csmall), "vp_conv5_smallin_dgrad_bf16x3: needs 64 big channels and 1 or 3 small channels");
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8, ntiles = B * tiles_x * tiles_y;
+  const int grid = ntiles < 512 ? ntiles : 512;                 // persistent: two workgroups (8 waves each) per CU
+  if (Csmall == 3)
+    hipLaunchKernelGGL((dgrad_rowk_kernel<3>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
+                       tiles_x * tiles_y, ntiles);
+  else
+    hipLaunchKernelGGL((dgrad_rowk_kernel<1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
+                       tiles_x * tiles_y, ntiles);
+  return check_launch("vp_conv5_smallin_dgrad_bf16x3");
 }
 
 }

@@ -460,7 +460,10 @@ class FusedVAEStep:
         # ---------------- backward ----------------
         inv_b = 1.0 / B
         dlogit = self._buf("g.dlogit", n_pix)
-        fin16 = x3 and Cf % 8 == 0 and C < 8          # final-conv dgrad on the bf16x3 kernel with dlogit padded to 8 channels
+        # final conv's input gradient: rows-in-K kernel of edge.hip (C = 1 | 3 image channels, 64 decoder channels), else the bf16x3
+        # halo kernel with dlogit padded to 8 channels
+        fin_rowk = x3 and Cf == 64 and C in (1, 3) and os.environ.get("VP_ROWK", "1") != "0"
+        fin16 = x3 and Cf % 8 == 0 and C < 8 and not fin_rowk
         if fin16:
             dlogit_s = self._sbuf("g.dlogit_s", B * S * S * 8)
             fp1s = self._sbuf("fin.p1s", Cf * 25 * 8)
@@ -483,7 +486,9 @@ class FusedVAEStep:
         big = max([B * F0, B * F1, n_pix] + [B * 4 * r[3] * r[3] * r[2] for r in dec_rec] + [B * r[3] * r[3] * r[2] for r in enc_rec]
                   + [B * S * S * Cf])
         gA, gB = self._buf("g.A", big), self._buf("g.B", big)
-        if fin16:
+        if fin_rowk:
+            bwd.add("vp_conv5_smallin_dgrad_bf16x3", P(dlogit), P(fin.weight), P(gA), B, S, S, C, Cf, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
+        elif fin16:
             bwd.add("vp_conv5_scatter_bf16x3", P(dlogit_s), P(fp1s), P(gA), B, S, S, 8, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         else:
             bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
