@@ -25,7 +25,7 @@
 namespace vp {
 
 template <int NOUT, int TH>
-__global__ void __launch_bounds__(256, 1) wgrad_tapm_kernel(const float* __restrict__ u, const float* __restrict__ dlogit,
+__global__ void __launch_bounds__(256, 2) wgrad_tapm_kernel(const float* __restrict__ u, const float* __restrict__ dlogit,
                                                             float* __restrict__ slab, int H, int W, int bands_per_img) {
   constexpr int C = 64, NCOL = 25 * NOUT, MT = (NCOL + 31) / 32;
   constexpr int SS = 64;                                   // pixels per staged super-step (4 MFMA k-steps)
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_tapm_kernel(const float* __restr
   }
 }
 
-constexpr int TAPM_TH = 16;
+constexpr int TAPM_TH = 8;        // band height: 8 rows = two workgroups per CU (16 rows, one per CU, left too few loads in flight: 57 us)
 
 bool tapm_wgrad_applicable(const ConvGeom& g) {
   static const bool on = [] { const char* e = getenv("VP_TAPM"); return !e || atoi(e) != 0; }();
@@ -311,7 +311,7 @@ int vp_conv5_smallout_wgrad_bf16x3(const float* big, const float* small, float* 
   VP_REQUIRE(big && small && dw_ref && ws && B > 0 && H > 0 && W > 0, "vp_conv5_smallout_wgrad_bf16x3: bad arguments");
   VP_REQUIRE(((uintptr_t)big & 15) == 0, "vp_conv5_smallout_wgrad_bf16x3: the activation must be 16-byte aligned");
   const ConvGeom g = make_geom(B, H, W, Csmall, Cbig, 1);
-  VP_REQUIRE(tapm_wgrad_applicable(g), "vp_conv5_smallout_wgrad_bf16x3: needs 64 input channels, 1 or 3 outputs, width a multiple of 64, height of 16");
+  VP_REQUIRE(tapm_wgrad_applicable(g), "vp_conv5_smallout_wgrad_bf16x3: needs 64 input channels, 1 or 3 outputs, width a multiple of 64, height of 8");
   if (ws_bytes < tapm_wgrad_ws_floats(g) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_smallout_wgrad_bf16x3: workspace too small");
   return tapm_wgrad_launch(big, small, dw_ref, g, (float*)ws, (hipStream_t)stream);
 }
