@@ -126,3 +126,37 @@ def test_fmt_producers_with_format_0_are_bit_identical():
     got = ops.unsplit(dxs, ops.SPLIT_F16) / 1024.0
     ref = outs[0][0].permute(0, 2, 3, 1).reshape(-1)
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+def test_engine_reports_saturated_gradient_planes():
+    """FusedVAEStep(precision="f16x2").f16_saturated(): zero at the default gradient scale, non-zero when the scale is absurd."""
+    from tests.test_gpu_engine import build
+    from oracle import ref_cpu as O
+    import vae_play_amd as V
+    from vae_play_amd import engine, optim
+    C, S, z, B = 3, 32, 16, 8
+    x, eps = O.synthetic_batch(B, C, S, z)
+    vae, opt, fused, p0, L = build(C, S, z, B, precision="f16x2")
+    fused.forward_backward(x.to(DEV), eps.to(DEV))
+    assert fused.f16_saturated() == 0
+    g_ok = {n: q.grad.detach().clone() for n, q in vae.named_parameters()}
+    vae2 = V.VAE(S, z, C, init_rule=False)
+    vae2.load_state_dict(p0)
+    vae2.to(DEV).train()
+    opt2 = optim.Adam(vae2.parameters(), lr=1e-4)
+    bad = engine.FusedVAEStep(vae2, opt2, B, S, C, precision="f16x2", grad_scale16=float(2 ** 40))
+    bad.forward_backward(x.to(DEV), eps.to(DEV))
+    assert bad.f16_saturated() > 0
+    # ... and a smaller power of two changes nothing but rounding
+    vae3 = V.VAE(S, z, C, init_rule=False)
+    vae3.load_state_dict(p0)
+    vae3.to(DEV).train()
+    opt3 = optim.Adam(vae3.parameters(), lr=1e-4)
+    low = engine.FusedVAEStep(vae3, opt3, B, S, C, precision="f16x2", grad_scale16=256.0)
+    low.forward_backward(x.to(DEV), eps.to(DEV))
+    assert low.f16_saturated() == 0
+    for n, q in vae3.named_parameters():
+        a, b = q.grad.double(), g_ok[n].double()
+        assert ((a - b).pow(2).sum().sqrt() / b.pow(2).sum().sqrt()).item() <= 2e-3, n
+    with pytest.raises(ValueError):
+        engine.FusedVAEStep(vae3, opt3, B, S, C, precision="f16x2", grad_scale16=1000.0)

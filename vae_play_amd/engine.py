@@ -495,6 +495,7 @@ class FusedVAEStep:
         cur, other = gA, gB
         # split gradient (output of BN backward) for the 16-bit kernels, two buffers used alternately
         gS2 = [self._sbuf("g.S0", big), self._sbuf("g.S1", big)] if x3 else [None, None]
+        self._grad_planes = gS2 if x2 else []
         gs_last = [None, None]      # side event of the weight gradient that last read each buffer
         gs_turn = [0]
 
@@ -732,6 +733,17 @@ class FusedVAEStep:
                 t = static
             for args, i in slots:
                 args[i] = c_void_p(t.data_ptr())
+
+    def f16_saturated(self) -> int:
+        """precision="f16x2" diagnostics (a host sync; not on the step's path): how many elements of the fp16 gradient planes sit at
+        +-65504, i.e. |g| * grad_scale16 overflowed fp16's range in the last step and was clamped.  The two ping-pong buffers hold
+        the last two layers' planes (earlier layers were overwritten): a non-zero count means grad_scale16 is too large for this
+        model / loss scale -- lower it (powers of two; 4096 leaves |g| < 16)."""
+        n = 0
+        for t in getattr(self, "_grad_planes", []):
+            hi = t[0].view(torch.float16)
+            n += int((hi.abs() >= 65504.0).sum().item())
+        return n
 
     def sync_counters(self):
         """Advance BatchNorm ``num_batches_tracked`` buffers (bookkeeping only; kept off the hot path)."""
