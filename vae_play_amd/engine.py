@@ -848,7 +848,7 @@ class FusedVAEStep:
             for w in works:
                 if w is not None:
                     w.wait()
-        elif self.world == 1 and self._outer_adam():
+        elif self.world == 1 and self._graph is None and self._outer_adam():      # (a captured graph replays the materialising plan)
             # one rank: encoder.fc.0's weight gradient (134 MB at config 3) is contracted from its two factors inside the Adam
             # kernel instead of being written by a GEMM and read back by the update; fc.0.weight.grad is NOT written by step()
             # (forward_backward() alone materialises every gradient).
