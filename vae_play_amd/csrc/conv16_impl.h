@@ -1,0 +1,275 @@
+// Shared by conv16.hip (bf16 pairs) and conv16_f16.hip (fp16 pairs): launch planning and the templated launchers of the three
+// split-operand families.  Everything here is static / a template, so that each translation unit instantiates only the problem
+// descriptors it dispatches (the fp16 modes live in their own object file: the two compile in parallel).
+#pragma once
+#include <type_traits>
+#include "common.h"
+#include "igemm16p.h"
+#include "halo.h"
+#include "narrow.h"
+#include "split.h"
+
+using namespace vp;
+
+
+// VP_HALO=0 sends the narrow-channel layers back to the implicit-GEMM kernels (A/B runs)
+// XCD-aware tile order (igemm16.h): valid when the row-tile count is a multiple of 8 and there are >= 2 column tiles
+static int xcd_map_for(long M, long N, int gz) {
+  const char* e = getenv("VP_XCD_MAP");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0) return 0;
+  const Tile16 t = choose_tile16(M, N, gz);
+  const long gx = (M + t.bm - 1) / t.bm, gy = (N + t.bn - 1) / t.bn;
+  if (mode == 2) return (gx % 8 == 0 && gx >= 16) ? 2 : 0;      // band order (igemm16.h): any column-tile / z count
+  return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
+}
+
+static bool halo_enabled() {
+  static const bool on = [] { const char* e = getenv("VP_HALO"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
+// layers with fewer output tiles than this split K in two (A/B knob VP_CONV_SPLIT_TILES)
+static long conv_split_tiles() {
+  const char* e = getenv("VP_CONV_SPLIT_TILES");
+  return e ? atol(e) : 384;
+}
+
+// Kernel choice for a plain 5x5 VAE layer on split planes: the pipelined LDS-DMA kernel (igemm16p.h, bit-identical results) takes
+// the shapes where its 256x256 eight-wave tile fills the chip -- N a multiple of 256 and at least one workgroup per CU, i.e. the
+// N >= 256 layers from ~128 images per GPU on (+5-10 % there, profiles/r02_notes.md); everything else stays on igemm16_kernel.
+// VP_IGEMM16P=0 disables it, VP_IGEMM16P_CFG=<n> forces configuration n of igemm16p.h wherever it applies (experiments).
+struct Launch16 { int pcfg, bm, bn; };
+static Launch16 plan16(long M, long N, int gz, int ctile, int nsplit, size_t plane_elems_a, size_t plane_elems_b, long kmin) {
+  const Tile16 t = choose_tile16(M, N, gz);
+  Launch16 l = {PCFG_NONE, t.bm, t.bn};
+  static const int mode = [] { const char* e = getenv("VP_IGEMM16P"); return e ? atoi(e) : 1; }();
+  static const int forced = [] { const char* e = getenv("VP_IGEMM16P_CFG"); return e ? atoi(e) : 0; }();
+  if (!mode || nsplit != 1 || ctile % 32 != 0 || kmin / 32 < 4) return l;
+  if (plane_elems_a >= ((size_t)1 << 29) || plane_elems_b >= ((size_t)1 << 29)) return l;      // 32-bit byte offsets of both planes
+  int cfg = PCFG_NONE;
+  if (forced > PCFG_NONE && forced < PCFG_COUNT) cfg = forced;
+  else if (N % 256 == 0 && M >= 256 && ((M + 255) / 256) * (N / 256) * gz >= 256) cfg = PCFG_256x256_S2;
+  if (cfg == PCFG_NONE) return l;
+  int bm, bn;
+  pcfg_tile(cfg, bm, bn);
+  if (bn > N || bm > M) return l;
+  l.pcfg = cfg; l.bm = bm; l.bn = bn;
+  return l;
+}
+static int xcd_map_tile(long M, long N, int bm, int bn) {
+  const char* e = getenv("VP_XCD_MAP");
+  if (e && atoi(e) == 0) return 0;
+  const long gx = (M + bm - 1) / bm, gy = (N + bn - 1) / bn;
+  return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
+}
+
+// split-K decisions (shared by the launchers and by the statistics plan)
+static int gather_nsplit(long M, int N, int K, int Cbig, bool plain5, bool has_bias, int act) {
+  // few output tiles and a long K (the 8x8-resolution layers: 256 workgroups = one per CU): split K in two and
+  // accumulate both halves with fp32 atomics onto a zeroed output (two addends: the sum does not depend on order)
+  const long tiles = ((M + 127) / 128) * ((N + 63) / 64);
+  return (plain5 && !has_bias && act == VP_ACT_NONE && Cbig % 64 == 0 && tiles < conv_split_tiles() && K >= 4096) ? 2 : 1;
+}
+static int scatter_nsplit(long M, int N, int Csmall, int stride, bool plain5) {
+  const long tiles = ((M + 127) / 128) * ((N + 63) / 64) * stride * stride;
+  return (plain5 && Csmall % 64 == 0 && tiles < conv_split_tiles() && 4 * Csmall >= 1024) ? 2 : 1;
+}
+
+struct BnBwdArgs { const float *x, *mean, *rstd, *gamma, *beta; float* slab; int act; };
+
+template <class PF>
+static int gather16_t(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws, int Hb,
+                      int Wb, int Cbig, int Csmall, int ks, int stride, int act, bool plain5, vp_stream stream, float* stat = nullptr,
+                      const BnBwdArgs* bb = nullptr, float alpha = 1.f) {
+  PF p;
+  p.alpha = alpha;
+  p.zero = vp_zero_page();
+  p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  p.big = (const u16*)big_split; p.big_plane = (size_t)B * p.g.Hb * p.g.Wb * Cbig;
+  p.w = (const u16*)w_p0_split; p.w_plane = (size_t)Csmall * Cbig * p.g.nt;
+  p.bias = bias; p.out = small_out; p.act = act;
+  p.M = B * Hs * Ws; p.N = Csmall; p.K = p.g.nt * Cbig;
+  p.nsplit = gather_nsplit(p.M, p.N, p.K, Cbig, plain5, bias != nullptr, act);
+  p.stat = stat;
+  if ((stat || bb) && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_gather_{stats,bnbwd}_bf16x3: this shape splits K");
+  if (bb) { p.bx = bb->x; p.bmean = bb->mean; p.brstd = bb->rstd; p.bgamma = bb->gamma; p.bbeta = bb->beta; p.bsum = bb->slab; p.bact = bb->act; }
+  p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
+  if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
+  if constexpr (std::is_same<PF, ProbF16>::value) {
+    const Launch16 l = plan16(p.M, p.N, p.nsplit, Cbig, p.nsplit, p.big_plane, p.w_plane, p.k_per_split);
+    if (l.pcfg != PCFG_NONE) {
+      PF16 q;
+      static_cast<ProbF16&>(q) = p;
+      q.xcd_map = xcd_map_tile(p.M, p.N, l.bm, l.bn);
+      launch_igemm16p(q, l.pcfg, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig, true, false);
+      return check_launch("vp_conv_gather_bf16x3(pipelined)");
+    }
+  }
+  p.xcd_map = xcd_map_for(p.M, p.N, p.nsplit);
+  launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig);
+  return check_launch("vp_conv_gather_bf16x3");
+}
+
+template <class PT>
+static int scatter16_t(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb, int Csmall,
+                       int Cbig, int ks, int stride, bool plain5, vp_stream stream, float* stat = nullptr, const BnBwdArgs* bb = nullptr,
+                       float alpha = 1.f) {
+  PT p;
+  p.alpha = alpha;
+  p.zero = vp_zero_page();
+  p.g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
+  p.w = (const u16*)w_p1_split; p.w_plane = (size_t)Csmall * Cbig * p.g.nt;
+  p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
+  p.nsplit = scatter_nsplit(p.M, p.N, Csmall, stride, plain5);
+  p.stat = stat;
+  if ((stat || bb) && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_scatter_{stats,bnbwd}_bf16x3: this shape splits K");
+  if (bb) { p.bx = bb->x; p.bmean = bb->mean; p.brstd = bb->rstd; p.bgamma = bb->gamma; p.bbeta = bb->beta; p.bsum = bb->slab; p.bact = bb->act; }
+  if (p.nsplit == 2 &&
+      hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
+  if constexpr (std::is_same<PT, ProbT16>::value) {
+    const Launch16 l = plan16(p.M, p.N, stride * stride * p.nsplit, Csmall, p.nsplit, p.small_plane, p.w_plane, (long)stride * stride * Csmall);
+    if (l.pcfg != PCFG_NONE && stride == 2) {
+      PT16 q;
+      static_cast<ProbT16&>(q) = p;
+      q.xcd_map = xcd_map_tile(p.M, p.N, l.bm, l.bn);
+      launch_igemm16p(q, l.pcfg, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall, true, false);
+      return check_launch("vp_conv_scatter_bf16x3(pipelined)");
+    }
+  }
+  p.xcd_map = xcd_map_for(p.M, p.N, stride * stride * p.nsplit);
+  launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
+  return check_launch("vp_conv_scatter_bf16x3");
+}
+
+template <class PW>
+static int wgrad16_t(const void* big_split, const void* small_split, float* dw_ref, const ConvGeom& g, int ns, void* ws, vp_stream stream,
+                     float alpha = 1.f) {
+  const int B = g.B, Hs = g.Hs, Ws = g.Ws, Cbig = g.Cb, Csmall = g.Cs;
+  PW p;
+  p.alpha = alpha;
+  p.zero = vp_zero_page();
+  p.g = g;
+  p.big = (const u16*)big_split; p.big_plane = (size_t)B * g.Hb * g.Wb * Cbig;
+  p.small = (const u16*)small_split; p.small_plane = (size_t)B * Hs * Ws * Csmall;
+  p.slab = (float*)ws; p.M = Csmall; p.N = Cbig; p.K = B * Hs * Ws;
+  p.nsplit = ns;
+  const int per = (p.K + ns - 1) / ns;
+  p.k_per_split = ((per + 31) / 32) * 32;
+  launch_igemm16(p, p.M, p.N, g.nt * ns, (hipStream_t)stream);
+  int rc = check_launch("vp_conv_wgrad_bf16x3(main)");
+  if (rc) return rc;
+  return slab_reduce_launch((const float*)ws, dw_ref, Csmall, Cbig, ns, (hipStream_t)stream, g.nt);
+}
+
+
+// ---- BatchNorm statistics from the convolution epilogue -----------------------------------------------------------------
+// A 5x5 VAE layer on the split-bf16 kernels can emit {pivot, sum(x - pivot), sum((x - pivot)^2)} per (workgroup, output channel)
+// from its accumulators (igemm16.h epilogue_stats32); one finaliser launch then produces mean / rstd / running statistics.
+// This replaces bn_partial_kernel<0>, i.e. one full read of the activation per BatchNorm layer.
+struct StatPlan { int ok, bm, tiles_m, gz, N; long M, R; };
+
+static StatPlan stat_plan(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int stride, bool x2 = false) {
+  StatPlan sp = {0, 0, 0, 0, 0, 0, 0};
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || Cbig <= 0 || Csmall <= 0 || (stride != 1 && stride != 2)) return sp;
+  if (Cbig % 8 != 0 || Csmall % 8 != 0) return sp;
+  sp.M = (long)B * Hs * Ws;
+  if (family == 0) {
+    if (!x2 && halo_enabled() && halo_gather_kind(B, Hs, Ws, Cbig, Csmall, stride)) return sp;
+    sp.N = Csmall;
+    if (gather_nsplit(sp.M, sp.N, 25 * Cbig, Cbig, true, false, VP_ACT_NONE) != 1) return sp;
+    sp.gz = 1;
+    sp.R = sp.M;
+  } else {
+    if (!x2 && halo_enabled() && halo_scatter_kind(B, Hs, Ws, Csmall, Cbig, stride)) return sp;
+    sp.N = Cbig;
+    if (scatter_nsplit(sp.M, sp.N, Csmall, stride, true) != 1) return sp;
+    sp.gz = stride * stride;
+    sp.R = sp.M * stride * stride;
+  }
+  const size_t act_plane = family == 0 ? (size_t)sp.M * stride * stride * Cbig : (size_t)sp.M * Csmall;
+  const Launch16 l = family == 0 ? plan16(sp.M, sp.N, sp.gz, Cbig, 1, act_plane, (size_t)Csmall * Cbig * 25, 25L * Cbig)
+                                 : plan16(sp.M, sp.N, sp.gz, Csmall, 1, act_plane, (size_t)Csmall * Cbig * 25, (long)stride * stride * Csmall);
+  sp.bm = (!x2 && l.pcfg != PCFG_NONE && !(family == 1 && stride != 2)) ? l.bm : choose_tile16(sp.M, sp.N, sp.gz).bm;
+  sp.tiles_m = (int)((sp.M + sp.bm - 1) / sp.bm);
+  sp.ok = 1;
+  return sp;
+}
+
+// ---- argument checks + dispatch of the three families; F16 = 0: bf16 pairs (three products), 2 | 3: fp16 pairs, products per fragment pair
+template <int F16>
+static int gather16(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws, int Hb,
+                    int Wb, int Cbig, int Csmall, int ks, int stride, int act, vp_stream stream, float alpha = 1.f) {
+  VP_REQUIRE(big_split && w_p0_split && small_out, "vp_conv_gather_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Cbig % 8 == 0, "vp_conv_gather_bf16x3: Cbig must be a multiple of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv_gather_bf16x3: stride must be 1 or 2");
+  VP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "vp_conv_gather_bf16x3: kernel size must be 1, 3 or 5");
+  VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv_gather_bf16x3: epilogue supports none|sigmoid");
+  const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
+  if constexpr (F16 != 0) {    // fp16-pair planes, f16 = products per fragment pair: always the implicit-GEMM kernels (the halo kernels read bf16 pairs)
+    VP_REQUIRE(alpha > 0.f, "vp_conv_gather_f16: out_scale must be positive");
+#define VP_G16(PF, P5) gather16_t<PF>(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, act, P5, stream, nullptr, nullptr, alpha)
+    if constexpr (F16 == 2) return plain5 ? VP_G16(ProbF16X, true) : VP_G16(ProbF16KX, false);
+    else return plain5 ? VP_G16(ProbF16H, true) : VP_G16(ProbF16KH, false);
+#undef VP_G16
+  } else {
+  if (plain5 && halo_enabled())
+    if (const int kind = halo_gather_kind(B, Hs, Ws, Cbig, Csmall, stride))
+      return halo_gather_launch(kind, big_split, w_p0_split, bias, small_out, B, Hs, Ws, Cbig, Csmall, stride, act, (hipStream_t)stream);
+  if (!plain5) return gather16_t<ProbF16K>(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, act, false, stream);
+  return gather16_t<ProbF16>(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, act, true, stream);
+  }
+}
+
+template <int F16>
+static int scatter16(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb, int Csmall,
+                     int Cbig, int ks, int stride, vp_stream stream, float alpha = 1.f) {
+  VP_REQUIRE(small_split && w_p1_split && big_out, "vp_conv_scatter_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig > 0 && Csmall > 0 && Csmall % 8 == 0, "vp_conv_scatter_bf16x3: Csmall must be a multiple of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv_scatter_bf16x3: stride must be 1 or 2");
+  VP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "vp_conv_scatter_bf16x3: kernel size must be 1, 3 or 5");
+  const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
+  if constexpr (F16 != 0) {
+    VP_REQUIRE(alpha > 0.f, "vp_conv_scatter_f16: out_scale must be positive");
+#define VP_S16(PT, P5) scatter16_t<PT>(small_split, w_p1_split, big_out, B, Hs, Ws, Hb, Wb, Csmall, Cbig, ks, stride, P5, stream, nullptr, nullptr, alpha)
+    if constexpr (F16 == 2) return plain5 ? VP_S16(ProbT16X, true) : VP_S16(ProbT16KX, false);
+    else return plain5 ? VP_S16(ProbT16H, true) : VP_S16(ProbT16KH, false);
+#undef VP_S16
+  } else {
+  if (plain5 && halo_enabled())
+    if (const int kind = halo_scatter_kind(B, Hs, Ws, Csmall, Cbig, stride))
+      return halo_scatter_launch(kind, small_split, w_p1_split, big_out, B, Hs, Ws, Csmall, Cbig, (hipStream_t)stream);
+  if (!plain5) return scatter16_t<ProbT16K>(small_split, w_p1_split, big_out, B, Hs, Ws, Hb, Wb, Csmall, Cbig, ks, stride, false, stream);
+  return scatter16_t<ProbT16>(small_split, w_p1_split, big_out, B, Hs, Ws, Hb, Wb, Csmall, Cbig, ks, stride, true, stream);
+  }
+}
+
+template <int F16>
+static int wgrad16(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
+                   int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream, float alpha = 1.f) {
+  VP_REQUIRE(big_split && small_split && dw_ref && ws, "vp_conv_wgrad_bf16x3: null pointer");
+  VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig % 8 == 0 && Csmall % 8 == 0 && Cbig > 0 && Csmall > 0,
+             "vp_conv_wgrad_bf16x3: channel counts must be multiples of 8");
+  VP_REQUIRE(stride == 1 || stride == 2, "vp_conv_wgrad_bf16x3: stride must be 1 or 2");
+  VP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "vp_conv_wgrad_bf16x3: kernel size must be 1, 3 or 5");
+  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  const int ns = wgrad_nsplit(g);
+  if (ws_bytes < wgrad_slab_floats(g, ns) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv_wgrad_bf16x3: workspace too small");
+  const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
+  if constexpr (F16 != 0) {
+    static_assert(F16 == 0 || F16 == 2, "weight gradients have no 3-product fp16 form");
+    VP_REQUIRE(alpha > 0.f, "vp_conv_wgrad_f16x2: out_scale must be positive");
+    if (!plain5) return wgrad16_t<ProbW16KX>(big_split, small_split, dw_ref, g, ns, ws, stream, alpha);
+    return wgrad16_t<ProbW16X>(big_split, small_split, dw_ref, g, ns, ws, stream, alpha);
+  } else {
+  if (!plain5) return wgrad16_t<ProbW16K>(big_split, small_split, dw_ref, g, ns, ws, stream);
+  return wgrad16_t<ProbW16>(big_split, small_split, dw_ref, g, ns, ws, stream);
+  }
+}
+
+// finaliser of the epilogue statistics (kernel in conv16.hip)
+int vp16_stats_finish(const StatPlan& sp, const float* slab, float eps, float momentum, float* mean, float* rstd, float* rm, float* rv,
+                      vp_stream stream);
