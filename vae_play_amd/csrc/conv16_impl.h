@@ -20,7 +20,7 @@ static int xcd_map_for(long M, long N, int gz) {
   if (mode == 0) return 0;
   const Tile16 t = choose_tile16(M, N, gz);
   const long gx = (M + t.bm - 1) / t.bm, gy = (N + t.bn - 1) / t.bn;
-  if (mode == 2) return (gx % 8 == 0 && gx >= 16) ? 2 : 0;      // band order (igemm16.h): any column-tile / z count
+  if (mode == 2 || mode == 3) return (gx % 8 == 0 && gx >= 16) ? mode : 0;      // band orders (igemm16.h): any column-tile / z count
   return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
 }
 

@@ -543,6 +543,12 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       tx = r * (int)(gridDim.x >> 3) + q / inner;
       ty = yz % (int)gridDim.y;
       tz = yz / (int)gridDim.y;
+    } else if (p.xcd_map == 3) {
+      // band order inside every z slice (phases / K halves stay separate launches in time, as in the default order)
+      const int hid = blockIdx.x + gridDim.x * blockIdx.y;
+      const int r = hid & 7, q = hid >> 3;
+      tx = r * (int)(gridDim.x >> 3) + q / (int)gridDim.y;
+      ty = q % (int)gridDim.y;
     }
   }
   const int m0 = tx * BM, n0 = ty * BN;
