@@ -168,6 +168,13 @@ int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float*
                           void* ws, size_t ws_bytes, vp_stream stream);
 /* producers of split tensors fused into the elementwise passes (y / dx / out may be NULL when only
  * the split copy is wanted) */
+/* nn.BatchNorm1d(momentum=0.9) + activation behind nn.Linear (models/networks.py:66-67,89-90), forward and backward, for at most
+ * 64 rows (the batch): statistics, finalisation and the normalised output / the two channel sums and the input gradient in ONE
+ * launch each, bit-identical to vp_bn_stats_f32 + vp_bn_act_fwd_f32 and to vp_bn_act_bwd_f32 (same arithmetic, step for step). */
+int vp_bn_small_fwd_f32(const float* x, int R, int C, float eps, float momentum, const float* gamma, const float* beta, float* mean,
+                        float* rstd, float* running_mean, float* running_var, float* y, int act, float slope, vp_stream stream);
+int vp_bn_small_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        float* dx, float* dgamma, float* dbeta, int R, int C, int act, float slope, int batch_stats, vp_stream stream);
 int vp_bn_act_fwd_split_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             float* y, void* y_split, int R, int C, int act, float slope, vp_stream stream);
 int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, const float* rstd,

@@ -94,12 +94,12 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const float* __restrict
         if (MODE == 0) {
           const float d = xv[j] - mu[j];
           s0[j] += d;
-          s1[j] += d * d;
+          s1[j] = fmaf(d, d, s1[j]);           // (explicit fma here and in bn_small_*: the two paths must round identically)
         } else {
           const float xh = (xv[j] - mu[j]) * rs[j];
           const float g = gv[j] * act_grad_pre(fmaf(ga[j], xh, be[j]), act, slope);
           s0[j] += g;
-          s1[j] += g * xh;
+          s1[j] = fmaf(g, xh, s1[j]);
         }
       }
     };
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
     for (int j = 0; j < 4; ++j) {
       const float xh = (xv[j] - mu[j]) * rs[j];
       const float g = dv[j] * act_grad_pre(fmaf(ga[j], xh, be[j]), act, slope);
-      o[j] = ga[j] * rs[j] * (g - (k0[j] + xh * k1[j]));
+      o[j] = ga[j] * rs[j] * (g - fmaf(xh, k1[j], k0[j]));       // (explicit fma: bn_small_bwd_kernel must round identically)
     }
     if (dx) *reinterpret_cast<vp_f32x4*>(dx + off) = o;
     if (dx_split) store_split4(dx_split, n, off, o[0] * sscale, o[1] * sscale, o[2] * sscale, o[3] * sscale, sfmt);
@@ -427,6 +427,150 @@ inline BnGrid bn_apply_grid(int R, int C) {
   g.rows_per_chunk = (R + g.chunks_r - 1) / g.chunks_r;
   g.chunks_r = (R + g.rows_per_chunk - 1) / g.rows_per_chunk;
   return g;
+}
+
+
+// ---- BatchNorm over a handful of rows (the dense layers: R = batch <= 64) in ONE launch --------------------------------------------
+// nn.BatchNorm1d + F.relu behind nn.Linear (models/networks.py:66-67,89-90) normalises over the batch only: the three-launch form
+// (partial sums, finaliser, apply) is pure launch latency there (3 x ~6 us for 32 rows).  One workgroup owns 64 channels and all
+// rows; a thread keeps its <= 4 rows of 4 channels in registers.  The arithmetic is the three-launch path's, step for step (pivoted
+// fp32 sums in the same order, fp64 finalisation, bn_pre for the normalised value), so results are bit-identical to it.
+constexpr int BN_SMALL_R = 4 * BN_TY;       // 64 rows
+
+__global__ void __launch_bounds__(256) bn_small_fwd_kernel(const float* __restrict__ x, int R, int C, float eps, float momentum,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rm,
+                                                           float* __restrict__ rv, float* __restrict__ y, int act, float slope) {
+  __shared__ float sh[2][BN_TY][BN_CH + 4];
+  __shared__ float fin[2][BN_CH];
+  const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
+  const int c = blockIdx.x * BN_CH + tx * 4;
+  const bool cok = c < C;                     // C % 4 == 0: a quad is inside or outside
+  vp_f32x4 xv[4], pv = {0.f, 0.f, 0.f, 0.f};
+  if (cok) pv = *reinterpret_cast<const vp_f32x4*>(x + c);           // pivot = row 0
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = ty + BN_TY * k;
+    if (cok && r < R) {
+      xv[k] = *reinterpret_cast<const vp_f32x4*>(x + (size_t)r * C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = xv[k][j] - pv[j]; s0[j] += d; s1[j] = fmaf(d, d, s1[j]); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh[0][ty][tx * 4 + j] = s0[j]; sh[1][ty][tx * 4 + j] = s1[j]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * BN_CH) {
+    const int which = threadIdx.x / BN_CH, cc = threadIdx.x % BN_CH;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_TY; ++k) s += sh[which][k][cc];
+    fin[which][cc] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < BN_CH) {
+    const int cc = threadIdx.x, cg = blockIdx.x * BN_CH + cc;
+    if (cg < C) {
+      const double ms = (double)fin[0][cc] / R;
+      double var = (double)fin[1][cc] / R - ms * ms;
+      if (var < 0.0) var = 0.0;
+      const double m = (double)x[cg] + ms;
+      const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+      mean[cg] = mf;
+      rstd[cg] = rf;
+      if (rm) rm[cg] = (1.f - momentum) * rm[cg] + momentum * mf;
+      if (rv) {
+        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        rv[cg] = (1.f - momentum) * rv[cg] + momentum * (float)unb;
+      }
+      fin[0][cc] = mf;
+      fin[1][cc] = rf;
+    }
+  }
+  __syncthreads();
+  if (!cok || !y) return;
+  float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = fin[0][tx * 4 + j]; rs[j] = fin[1][tx * 4 + j];
+    ga[j] = gamma ? gamma[c + j] : 1.f; be[j] = beta ? beta[c + j] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = ty + BN_TY * k;
+    if (r < R) {
+      vp_f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = act_apply(bn_pre(xv[k][j], mu[j], rs[j], ga[j], be[j]), act, slope);
+      *reinterpret_cast<vp_f32x4*>(y + (size_t)r * C + c) = o;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int R, int C, float invR, int act, float slope) {
+  __shared__ float sh[2][BN_TY][BN_CH + 4];
+  __shared__ float fin[2][BN_CH];
+  const int tx = threadIdx.x % BN_TX, ty = threadIdx.x / BN_TX;
+  const int c = blockIdx.x * BN_CH + tx * 4;
+  const bool cok = c < C;
+  float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = cok ? mean[c + j] : 0.f; rs[j] = cok ? rstd[c + j] : 0.f;
+    ga[j] = (cok && gamma) ? gamma[c + j] : 1.f; be[j] = (cok && beta) ? beta[c + j] : 0.f;
+  }
+  float gq[4][4], xh[4][4];
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = ty + BN_TY * k;
+    if (cok && r < R) {
+      const vp_f32x4 xv = *reinterpret_cast<const vp_f32x4*>(x + (size_t)r * C + c);
+      const vp_f32x4 dv = *reinterpret_cast<const vp_f32x4*>(dy + (size_t)r * C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[k][j] = (xv[j] - mu[j]) * rs[j];
+        gq[k][j] = dv[j] * act_grad_pre(fmaf(ga[j], xh[k][j], be[j]), act, slope);
+        s0[j] += gq[k][j];
+        s1[j] = fmaf(gq[k][j], xh[k][j], s1[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh[0][ty][tx * 4 + j] = s0[j]; sh[1][ty][tx * 4 + j] = s1[j]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * BN_CH) {
+    const int which = threadIdx.x / BN_CH, cc = threadIdx.x % BN_CH;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_TY; ++k) s += sh[which][k][cc];
+    fin[which][cc] = s;
+    const int cg = blockIdx.x * BN_CH + cc;
+    if (cg < C) {
+      if (which == 0 && dbeta) dbeta[cg] = s;
+      if (which == 1 && dgamma) dgamma[cg] = s;
+    }
+  }
+  __syncthreads();
+  if (!cok) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = ty + BN_TY * k;
+    if (r < R) {
+      vp_f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float k0 = fin[0][tx * 4 + j] * invR, k1 = fin[1][tx * 4 + j] * invR;
+        o[j] = ga[j] * rs[j] * (gq[k][j] - fmaf(xh[k][j], k1, k0));
+      }
+      *reinterpret_cast<vp_f32x4*>(dx + (size_t)r * C + c) = o;
+    }
+  }
 }
 
 inline size_t bn_ws_floats(int R, int C) {
@@ -620,6 +764,24 @@ int vp_bn_act_bwd_apply_split_f32(const float* x, const float* dy, const float* 
   hipLaunchKernelGGL(bn_act_bwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c), dim3(256), 0, (hipStream_t)stream, x, dy, mean, rstd, gamma, beta,
                      sums, sums + C, dx, (u16_t*)dx_split, R, C, ga.rows_per_chunk, invR, act, slope);
   return check_launch("vp_bn_act_bwd_apply_split_f32");
+}
+
+int vp_bn_small_fwd_f32(const float* x, int R, int C, float eps, float momentum, const float* gamma, const float* beta, float* mean,
+                        float* rstd, float* running_mean, float* running_var, float* y, int act, float slope, vp_stream stream) {
+  VP_REQUIRE(x && mean && rstd && R > 0 && C > 0, "vp_bn_small_fwd_f32: bad arguments");
+  VP_REQUIRE(R <= BN_SMALL_R && C % 4 == 0, "vp_bn_small_fwd_f32: at most 64 rows, C a multiple of 4 (use vp_bn_stats_f32 + vp_bn_act_fwd_f32)");
+  hipLaunchKernelGGL(bn_small_fwd_kernel, dim3((C + BN_CH - 1) / BN_CH), dim3(256), 0, (hipStream_t)stream, x, R, C, eps, momentum, gamma, beta,
+                     mean, rstd, running_mean, running_var, y, act, slope);
+  return check_launch("vp_bn_small_fwd_f32");
+}
+
+int vp_bn_small_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        float* dx, float* dgamma, float* dbeta, int R, int C, int act, float slope, int batch_stats, vp_stream stream) {
+  VP_REQUIRE(x && dy && mean && rstd && dx && R > 0 && C > 0, "vp_bn_small_bwd_f32: bad arguments");
+  VP_REQUIRE(R <= BN_SMALL_R && C % 4 == 0, "vp_bn_small_bwd_f32: at most 64 rows, C a multiple of 4 (use vp_bn_act_bwd_f32)");
+  hipLaunchKernelGGL(bn_small_bwd_kernel, dim3((C + BN_CH - 1) / BN_CH), dim3(256), 0, (hipStream_t)stream, x, dy, mean, rstd, gamma, beta, dx,
+                     dgamma, dbeta, R, C, batch_stats ? 1.f / (float)R : 0.f, act, slope);
+  return check_launch("vp_bn_small_bwd_f32");
 }
 
 int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream) {

@@ -228,6 +228,7 @@ class FusedVAEStep:
             return x3 and cin % 8 == 0 and cout % 8 == 0
 
         fuse_stats = x3 and os.environ.get("VP_FUSE_BN_STATS", "1") != "0"
+        small_bn = os.environ.get("VP_BN_SMALL", "1") != "0"      # A/B knob: single-launch BatchNorm for <= 64 rows
 
         def bn_block(tag, x_buf, R, Cn, bn_mod, y_buf, y_split=None, conv=None):
             """stats + fused normalise/ReLU (fp32 and/or split output); returns the saved (mean, rstd).
@@ -255,6 +256,11 @@ class FusedVAEStep:
                     extra = (None,) if family == 0 else ()
                     tail = ((_ACT_NONE,) if family == 0 else ()) + (((FWD_PRODUCTS if family == 0 else DEC_FWD_PRODUCTS), 1.0) if x2 else ())
                     fwd.add(name.replace("_bf16x3", "_f16") if x2 else name, lead[0], lead[1], *extra, lead[2], *geom, *tail, flops=fl, tag=ctag)
+            if not fused and conv is None and y_split is None and R <= 64 and Cn % 4 == 0 and small_bn:
+                # the dense layers' BatchNorm1d (R = batch rows): statistics + finalisation + normalise/ReLU in ONE launch
+                fwd.add("vp_bn_small_fwd_f32", P(x_buf), R, Cn, eps_bn, mom, P(bn_mod.weight), P(bn_mod.bias), P(mean), P(rstd),
+                        P(bn_mod.running_mean), P(bn_mod.running_var), P(y_buf), _ACT_RELU, 0.0)
+                return mean, rstd, ws
             if not fused:
                 fwd.add("vp_bn_stats_f32", P(x_buf), R, Cn, eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean),
                         P(bn_mod.running_var), P(ws), ws.numel() * 4)
@@ -289,6 +295,10 @@ class FusedVAEStep:
             return sums
 
         def bn_block_bwd(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None, sums=None):
+            if sums is None and dx_split is None and R <= 64 and Cn % 4 == 0 and small_bn:
+                bwd.add("vp_bn_small_bwd_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(dx_buf),
+                        P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1)
+                return
             if sums is not None:
                 bwd.add("vp_bn_act_bwd_apply_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(sums),
                         P(dx_buf), P(dx_split), R, Cn, _ACT_RELU, 0.0, 1)
@@ -560,6 +570,10 @@ class FusedVAEStep:
         dh = self._buf("g.dh", B * 1024)
 
         def bn_block_bwd2(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None, sums=None):
+            if sums is None and dx_split is None and R <= 64 and Cn % 4 == 0 and small_bn:
+                bwd.add("vp_bn_small_bwd_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(dx_buf),
+                        P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1)
+                return
             if sums is not None:
                 bwd.add("vp_bn_act_bwd_apply_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(sums),
                         P(dx_buf), P(dx_split), R, Cn, _ACT_RELU, 0.0, 1)
