@@ -38,18 +38,22 @@ static long conv_split_tiles() {
 // Kernel choice for a plain 5x5 VAE layer on split planes: the pipelined LDS-DMA kernel (igemm16p.h, bit-identical results) takes
 // the shapes where its 256x256 eight-wave tile fills the chip -- N a multiple of 256 and at least one workgroup per CU, i.e. the
 // N >= 256 layers from ~128 images per GPU on (+5-10 % there, profiles/r02_notes.md); everything else stays on igemm16_kernel.
-// VP_IGEMM16P=0 disables it, VP_IGEMM16P_CFG=<n> forces configuration n of igemm16p.h wherever it applies (experiments).
+// It also takes the small layers (see plan16).  VP_IGEMM16P=0 disables it, =2 keeps only the 256x256 rule (A/B),
+// VP_IGEMM16P_CFG=<n> forces configuration n of igemm16p.h wherever it applies (experiments).
 struct Launch16 { int pcfg, bm, bn; };
 static Launch16 plan16(long M, long N, int gz, int ctile, int nsplit, size_t plane_elems_a, size_t plane_elems_b, long kmin) {
   const Tile16 t = choose_tile16(M, N, gz);
   Launch16 l = {PCFG_NONE, t.bm, t.bn};
   static const int mode = [] { const char* e = getenv("VP_IGEMM16P"); return e ? atoi(e) : 1; }();
   static const int forced = [] { const char* e = getenv("VP_IGEMM16P_CFG"); return e ? atoi(e) : 0; }();
-  if (!mode || nsplit != 1 || ctile % 32 != 0 || kmin / 32 < 4) return l;
+  if (!mode || ctile % 32 != 0 || kmin / 32 < 4) return l;
   if (plane_elems_a >= ((size_t)1 << 29) || plane_elems_b >= ((size_t)1 << 29)) return l;      // 32-bit byte offsets of both planes
   int cfg = PCFG_NONE;
-  if (forced > PCFG_NONE && forced < PCFG_COUNT) cfg = forced;
-  else if (N % 256 == 0 && M >= 256 && ((M + 255) / 256) * (N / 256) * gz >= 256) cfg = PCFG_256x256_S2;
+  if (forced > PCFG_NONE && forced < PCFG_COUNT) cfg = nsplit == 1 ? forced : PCFG_NONE;
+  else if (nsplit == 1 && N % 256 == 0 && M >= 256 && ((M + 255) / 256) * (N / 256) * gz >= 256) cfg = PCFG_256x256_S2;
+  // the small layers (8x8 / 16x16 resolution at 32 images: M*N <= 1 M outputs, where igemm16_kernel runs 64x64 / 128x64 tiles with
+  // K split in two): the pipelined 128x64 tile, same arithmetic bit for bit, is 4-10 % faster there (r02_a_kbench_m16_b32.log: c7b)
+  else if (mode != 2 && M * N <= (1L << 20) && N >= 128 && M >= 128) cfg = PCFG_128x64_S3;
   if (cfg == PCFG_NONE) return l;
   int bm, bn;
   pcfg_tile(cfg, bm, bn);
