@@ -609,14 +609,18 @@ class FusedVAEStep:
                 bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS, sums=pend)  # gS = d c_0 (split)
                 dwc = self._buf("enc0.dwc", Cout * KC)
                 ws0 = self._ws("enc0.wgws", lib.vp_conv_wgrad_bf16x3_workspace_bytes(B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1))
-                gs_last[k] = side_slot()
+                # the LAST weight gradient of the step stays on the main stream: on the side stream the join that follows it (and
+                # precedes the optimiser) finds both queues idle for ~18 us -- the latency of a dependency between two hardware
+                # queues (profiles/r02_notes.md) -- while here the side stream has long finished when the main stream joins it
+                last_main = os.environ.get("VP_LAST_WGRAD_MAIN", "1") != "0"
+                gs_last[k] = None if last_main else side_slot()
                 if x2:
                     bwd.add("vp_conv_wgrad_f16x2", P(xcol), P(gS), P(dwc), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, 1.0 / GS, P(ws0), ws0.numel() * 4,
                             flops=fl, tag="enc0.wgrad", side=gs_last[k])
                 else:
                     bwd.add("vp_conv_wgrad_bf16x3", P(xcol), P(gS), P(dwc), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, P(ws0), ws0.numel() * 4,
                             flops=fl, tag="enc0.wgrad", side=gs_last[k])
-                bwd.add("vp_unpack_dw_im2col5_f32", P(dwc), P(grad_of(blk.conv.weight)), Cout, Cin, side=side_slot())
+                bwd.add("vp_unpack_dw_im2col5_f32", P(dwc), P(grad_of(blk.conv.weight)), Cout, Cin, side=(None if last_main else side_slot()))
             elif enc16[i]:
                 k = next_gs(bwd)
                 gS = gS2[k]

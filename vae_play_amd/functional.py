@@ -20,7 +20,7 @@ from typing import Optional
 import torch
 from torch.autograd import Function
 
-from . import ops
+from . import _lib, ops
 from .ops import ACT_CODES, ACT_NONE, ACT_SIGMOID
 
 
@@ -65,6 +65,23 @@ class _Conv5(Function):
     def forward(ctx, x, weight, bias, stride: int, act: int):
         x = _cl(x)
         ctx.x16 = _use16(weight) and act in (ACT_NONE, ACT_SIGMOID)
+        ctx.cols = None
+        Cs, Cb = weight.shape[0], weight.shape[1]
+        if (_PRECISION == "bf16x3" and stride == 2 and Cb in (1, 3) and Cs % 8 == 0 and act == ACT_NONE and bias is None
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and os.environ.get("VP_EDGE_AUTOGRAD", "1") != "0"):
+            # first conv on a 1- / 3-channel image (models/networks.py:14 via :55): its im2col written once as split planes, then a
+            # 1x1 layer on the split-bf16 kernels for the forward pass and the weight gradient (as the fused step does)
+            B, _, H, W = x.shape
+            KC = _lib.load().vp_im2col5s2_cols(Cb)
+            xcol = ops.empty_split(B * (H // 2) * (W // 2) * KC, x)
+            _lib.call("vp_im2col5s2_split_f32", ops._p(x), ops._pv(xcol), B, Cb, H, W, 0, ops._stream())
+            w0s = ops.empty_split(Cs * KC, x)
+            _lib.call("vp_pack_w_im2col5_split", ops._p(weight.contiguous()), ops._pv(w0s), Cs, Cb, ops._stream())
+            y = ops.conv_gather_bf16x3(xcol, (B, KC, H // 2, W // 2), w0s, Cs, None, 1, 1, ACT_NONE)
+            ctx.cols = (KC, B, H, W)
+            ctx.stride, ctx.act, ctx.has_bias = stride, act, False
+            ctx.save_for_backward(xcol, weight, None)
+            return y
         if ctx.x16:
             xs = _split_of(x)
             p0, _ = ops.pack_w5_split(weight, True, False)
@@ -73,7 +90,17 @@ class _Conv5(Function):
             x = xs          # the split copy is what the weight gradient reads
         else:
             p0, _ = ops.pack_w5(weight, True, False)
-            y = ops.conv5_gather(x, p0, bias, stride, act)
+            # the image side of the final conv (64 -> 1 | 3 channels, models/networks.py:100-103) on the matrix cores: the edge
+            # kernels of the fused step (taps in the MFMA columns / rows, a kernel row per k-step) instead of the VALU kernels
+            ctx.edge = (_PRECISION == "bf16x3" and stride == 1 and weight.shape[1] == 64 and weight.shape[0] in (1, 3)
+                        and act in (ACT_NONE, ACT_SIGMOID) and os.environ.get("VP_EDGE_AUTOGRAD", "1") != "0")
+            if ctx.edge:
+                B, _, H, W = x.shape
+                y = ops.empty_cl(B, weight.shape[0], H, W, x)
+                _lib.call("vp_conv5_smallout_bf16x3", ops._p(x), ops._p(p0), ops._p(bias), ops._p(y), B, H, W, 64, weight.shape[0], act,
+                          ops._stream())
+            else:
+                y = ops.conv5_gather(x, p0, bias, stride, act)
         ctx.stride, ctx.act, ctx.has_bias = stride, act, bias is not None
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         return y
@@ -85,6 +112,19 @@ class _Conv5(Function):
         if ctx.act != ACT_NONE:
             dy = ops.act_bwd_from_y(y, dy, ctx.act)
         dx = dw = db = None
+        if ctx.cols is not None:
+            KC, B, H, W = ctx.cols
+            Cs, Cb = weight.shape[0], weight.shape[1]
+            if ctx.needs_input_grad[1]:
+                dys = ops.split_f32(dy)
+                dwc = ops.conv_wgrad_bf16x3(x, (B, KC, H // 2, W // 2), dys, tuple(dy.shape), 1, 1)      # [Cs][KC] in column order
+                dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+                _lib.call("vp_unpack_dw_im2col5_f32", ops._p(dwc), ops._p(dw), Cs, Cb, ops._stream())
+            if ctx.needs_input_grad[0]:           # (an image that requires a gradient: the padded split-bf16 scatter)
+                wpad = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 8 - Cb))
+                _, p1 = ops.pack_w5_split(wpad, False, True)
+                dx = ops.conv5_scatter_bf16x3(ops.split_f32(dy), dy.shape, p1, 8, ctx.stride)[:, :Cb]
+            return dx, dw, None, None, None
         if ctx.x16:
             dys = ops.split_f32(dy)
             if ctx.needs_input_grad[0]:
@@ -95,7 +135,12 @@ class _Conv5(Function):
         else:
             if ctx.needs_input_grad[0]:
                 Cs, Cb = weight.shape[0], weight.shape[1]
-                if _PRECISION == "bf16x3" and Cs < 8 and Cb % 8 == 0 and ctx.stride == 1:
+                if getattr(ctx, "edge", False):
+                    B, _, H, W = dy.shape
+                    dx = ops.empty_cl(B, Cb, H, W, dy)
+                    _lib.call("vp_conv5_smallin_dgrad_bf16x3", ops._p(dy), ops._p(weight.contiguous()), ops._p(dx), B, H, W, Cs, Cb,
+                              ops._stream())
+                elif _PRECISION == "bf16x3" and Cs < 8 and Cb % 8 == 0 and ctx.stride == 1:
                     # the image side of the final conv (1 or 3 channels): pad it to 8 channels and run the input gradient on
                     # the split-bf16 halo kernel like the fused engine does (the exact-f32 scatter with K = 25 * Cs is a 94 %
                     # padded MFMA tile: 494 us against ~60 us at 32 images of 128 x 128)
@@ -116,7 +161,16 @@ class _Conv5(Function):
                     _, p1 = ops.pack_w5(weight, False, True)
                     dx = ops.conv5_scatter(dy, p1, ctx.stride)
             if ctx.needs_input_grad[1]:
-                dw = ops.conv5_wgrad(x, dy, ctx.stride)
+                B, Cs, H, W = dy.shape
+                nb = (_lib.load().vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(B, H, W, weight.shape[1], Cs)
+                      if getattr(ctx, "edge", False) else 0)
+                if nb:
+                    ws = torch.empty(nb // 4, dtype=torch.float32, device=dy.device)
+                    dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+                    _lib.call("vp_conv5_smallout_wgrad_bf16x3", ops._p(x), ops._p(dy), ops._p(dw), B, H, W, weight.shape[1], Cs, ops._p(ws), nb,
+                              ops._stream())
+                else:
+                    dw = ops.conv5_wgrad(x, dy, ctx.stride)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             B, C, H, W = dy.shape
             db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C))
