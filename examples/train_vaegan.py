@@ -40,7 +40,7 @@ def train(args, epoch, net, optims, loader, dev):
         losses["loss_decoder"] = torch.sum(LAMBDA_MSE * mse) - (1.0 - LAMBDA_MSE) * losses["loss_discriminator"]
         losses["loss_aux"] = l1
         for o in optims.values():
-            o.zero_grad()
+            o.zero_grad(set_to_none=True)
         V.VaeGan.backward_all(losses["loss_recon"], losses["loss_encoder"], losses["loss_decoder"], losses["loss_discriminator"],
                               losses["loss_aux"])
         for o in optims.values():

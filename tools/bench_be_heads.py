@@ -38,7 +38,7 @@ def main():
     def step():
         out = net(feat)
         loss = N.be_loss(out["edges"], eimgs) + N.be_loss(out["masks"], bimgs)
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
         return loss

@@ -69,19 +69,19 @@ def main():
             pm = torch.cat([pr["masks"], pr["edges"]], dim=1)
         d_gt_adv, d_gt_aux = disc(torch.cat([dmasks, dedges], dim=1), dy)
         d_pr_adv, _ = disc(pm, dy)
-        opt_disc.zero_grad()
+        opt_disc.zero_grad(set_to_none=True)
         ((F.binary_cross_entropy(d_gt_adv, ones) + F.binary_cross_entropy(d_pr_adv, zeros)) * 0.5 + F.cross_entropy(d_gt_aux, dlabels)).backward()
         apply(opt_disc)
         pr = net(dimgs, dy)
         g_adv, g_aux = disc(torch.cat([pr["masks"], pr["edges"]], dim=1), dy)
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=True)
         l_gadv = F.binary_cross_entropy(g_adv, ones) * 2
         (NB.be_loss(pr["edges"], dedges) * 10 + NB.be_loss(pr["masks"], dmasks) * 10 + l_gadv + l_gadv * 5).backward()
         apply(opt)
         with torch.no_grad():
             ref = net(dimgs, dy)
         pr_ = net(dimgs)
-        opt_style.zero_grad()
+        opt_style.zero_grad(set_to_none=True)
         l_embed = (Fh.l1_loss(pr_["masks"], ref["masks"]) + Fh.l1_loss(pr_["edges"], ref["edges"])) * 2.0
         (NB.be_loss(pr_["masks"], dmasks) + NB.be_loss(pr_["edges"], dedges) + l_embed).backward()
         apply(opt_style)

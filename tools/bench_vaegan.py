@@ -25,7 +25,7 @@ def step(net, opts, x, targets, eps, z_p, V, lam, fused=True, dp=None):
     loss_disc = torch.sum(bo) + torch.sum(bp) + torch.sum(bs)
     loss_decoder = torch.sum(lam * mse) - (1.0 - lam) * loss_disc
     for o in opts:
-        o.zero_grad()
+        o.zero_grad(set_to_none=True)      # gradients are then written straight into the arena slices (functional._grad_out)
     if fused:
         V.VaeGan.backward_all(loss_recon, loss_encoder, loss_decoder, loss_disc, l1)
     else:

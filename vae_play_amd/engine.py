@@ -220,9 +220,10 @@ class FusedVAEStep:
                                           p1.data_ptr() if p1 is not None else None, Cs, Cb, Cs_pad, (2 if (x2 and not bf16) else 1) if split else 0))
 
         def grad_of(p: torch.nn.Parameter) -> torch.Tensor:
-            if p.grad is None:
+            arena = getattr(p, "_vp_arena", None)
+            if arena is None:
                 raise _lib.VaePlayHipError("parameter has no arena gradient; build the optimiser first")
-            return p.grad
+            return arena.grad_view(p)        # (not p.grad: optimizer.zero_grad(set_to_none=True) drops that attribute, not the slice)
 
         def use16(cin, cout):
             return x3 and cin % 8 == 0 and cout % 8 == 0

@@ -54,6 +54,25 @@ def _split_of(x: torch.Tensor) -> torch.Tensor:
     return ops.split_f32(x)
 
 
+def _grad_out(param) -> Optional[torch.Tensor]:
+    """Where a backward pass may WRITE ``param``'s gradient instead of returning a fresh tensor: its slice of the optimiser's flat
+    gradient arena, when the parameter lives in one (optim.FlatArena) and has no gradient yet (``module.zero_grad()`` of
+    train.py:68, or ``optimizer.zero_grad(set_to_none=True)``).  autograd's AccumulateGrad then adopts that view as ``.grad``
+    without a kernel, where it would otherwise add a fresh tensor onto the zeroed arena -- one small add per parameter tensor
+    and step (114 launches, 6 % of the VAE-GAN step).  A parameter used twice in one graph gets the view once (its hook clears
+    the marker after accumulation); further contributions take the ordinary path and are added by autograd."""
+    if param is None or param.grad is not None or not _DIRECT_GRADS:
+        return None
+    arena = getattr(param, "_vp_arena", None)
+    if arena is None or getattr(param, "_vp_pending", False) or torch.is_grad_enabled():
+        return None
+    param._vp_pending = True
+    return arena.grad_view(param)
+
+
+_DIRECT_GRADS = os.environ.get("VP_DIRECT_GRADS", "1") != "0"
+
+
 def _use16(weight) -> bool:
     return _PRECISION == "bf16x3" and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
 
@@ -102,6 +121,7 @@ class _Conv5(Function):
             else:
                 y = ops.conv5_gather(x, p0, bias, stride, act)
         ctx.stride, ctx.act, ctx.has_bias = stride, act, bias is not None
+        ctx.bias_param = bias
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         return y
 
@@ -118,7 +138,8 @@ class _Conv5(Function):
             if ctx.needs_input_grad[1]:
                 dys = ops.split_f32(dy)
                 dwc = ops.conv_wgrad_bf16x3(x, (B, KC, H // 2, W // 2), dys, tuple(dy.shape), 1, 1)      # [Cs][KC] in column order
-                dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+                dw = _grad_out(weight)
+                dw = dw if dw is not None else torch.empty_like(weight, memory_format=torch.contiguous_format)
                 _lib.call("vp_unpack_dw_im2col5_f32", ops._p(dwc), ops._p(dw), Cs, Cb, ops._stream())
             if ctx.needs_input_grad[0]:           # (an image that requires a gradient: the padded split-bf16 scatter)
                 wpad = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 8 - Cb))
@@ -131,7 +152,7 @@ class _Conv5(Function):
                 _, p1 = ops.pack_w5_split(weight, False, True)
                 dx = ops.conv5_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.stride)
             if ctx.needs_input_grad[1]:
-                dw = ops.conv5_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.stride)
+                dw = ops.conv5_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.stride, out=_grad_out(weight))
         else:
             if ctx.needs_input_grad[0]:
                 Cs, Cb = weight.shape[0], weight.shape[1]
@@ -166,14 +187,15 @@ class _Conv5(Function):
                       if getattr(ctx, "edge", False) else 0)
                 if nb:
                     ws = torch.empty(nb // 4, dtype=torch.float32, device=dy.device)
-                    dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+                    dw = _grad_out(weight)
+                    dw = dw if dw is not None else torch.empty_like(weight, memory_format=torch.contiguous_format)
                     _lib.call("vp_conv5_smallout_wgrad_bf16x3", ops._p(x), ops._p(dy), ops._p(dw), B, H, W, weight.shape[1], Cs, ops._p(ws), nb,
                               ops._stream())
                 else:
-                    dw = ops.conv5_wgrad(x, dy, ctx.stride)
+                    dw = ops.conv5_wgrad(x, dy, ctx.stride, out=_grad_out(weight))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             B, C, H, W = dy.shape
-            db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C))
+            db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C), out=_grad_out(ctx.bias_param))
         return dx, dw, db, None, None
 
 
@@ -209,13 +231,13 @@ class _ConvT5(Function):
                 p0, _ = ops.pack_w5_split(weight, True, False)
                 dx = ops.conv5_gather_bf16x3(dys, dy.shape, p0, weight.shape[0], None, ctx.stride, ACT_NONE)
             if ctx.needs_input_grad[1]:
-                dw = ops.conv5_wgrad_bf16x3(dys, tuple(dy.shape), x, ctx.xshape, ctx.stride)
+                dw = ops.conv5_wgrad_bf16x3(dys, tuple(dy.shape), x, ctx.xshape, ctx.stride, out=_grad_out(weight))
             return dx, dw, None
         if ctx.needs_input_grad[0]:
             p0, _ = ops.pack_w5(weight, True, False)
             dx = ops.conv5_gather(dy, p0, None, ctx.stride, ACT_NONE)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv5_wgrad(dy, x, ctx.stride)
+            dw = ops.conv5_wgrad(dy, x, ctx.stride, out=_grad_out(weight))
         return dx, dw, None
 
 
@@ -247,7 +269,10 @@ class _BatchNormAct(Function):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         dy = _cl(dy) if dy.dim() == 4 else dy.contiguous()
         need_affine = gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        dx, dgamma, dbeta = ops.bn_act_bwd(x, dy, mean, rstd, gamma, beta, ctx.act, ctx.slope, ctx.training, need_affine)
+        og = _grad_out(gamma) if (need_affine and ctx.needs_input_grad[1]) else None
+        ob = _grad_out(beta) if (need_affine and ctx.needs_input_grad[2]) else None
+        dx, dgamma, dbeta = ops.bn_act_bwd(x, dy, mean, rstd, gamma, beta, ctx.act, ctx.slope, ctx.training, need_affine,
+                                           out_dgamma=og, out_dbeta=ob)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -257,6 +282,7 @@ class _Linear(Function):
         x = x.contiguous()
         y = ops.linear_fwd(x, weight, bias)
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias
         ctx.save_for_backward(x, weight)
         return y
 
@@ -268,9 +294,9 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(dy, weight)
         if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(dy, x)
+            dw = ops.linear_wgrad(dy, x, out=_grad_out(weight))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy)
+            db = ops.colsum(dy, out=_grad_out(ctx.bias_param))
         return dx, dw, db
 
 
@@ -328,6 +354,7 @@ class _ConvK(Function):
             y = ops.conv_gather_bf16x3(xs, (B, Cip, H, W), p0, Cop, bp, ks, stride, ACT_NONE)
             ctx.pad = (Co, Ci, Cop, Cip)
             ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
+            ctx.bias_param = bias
             ctx.save_for_backward(xs, weight)
             return y[:, :Co] if Cop != Co else y
         if ctx.x16:                     # split-bf16 kernels (set_conv_precision("bf16x3"), channel counts multiples of 8)
@@ -339,6 +366,7 @@ class _ConvK(Function):
             p0, _ = ops.pack_w(weight, True, False)
             y = ops.conv_gather(x, p0, bias, ks, stride, ACT_NONE)
         ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
+        ctx.bias_param = bias
         ctx.save_for_backward(x, weight)
         return y
 
@@ -368,16 +396,16 @@ class _ConvK(Function):
                 _, p1 = ops.pack_w_split(weight, False, True)
                 dx = ops.conv_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.ks, ctx.stride, ctx.xshape[2], ctx.xshape[3])
             if ctx.needs_input_grad[1]:
-                dw = ops.conv_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.ks, ctx.stride)
+                dw = ops.conv_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.ks, ctx.stride, out=_grad_out(weight))
         else:
             if ctx.needs_input_grad[0]:
                 _, p1 = ops.pack_w(weight, False, True)
                 dx = ops.conv_scatter(dy, p1, ctx.ks, ctx.stride, x.shape[2], x.shape[3])
             if ctx.needs_input_grad[1]:
-                dw = ops.conv_wgrad(x, dy, ctx.ks, ctx.stride)
+                dw = ops.conv_wgrad(x, dy, ctx.ks, ctx.stride, out=_grad_out(weight))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             B, C, H, W = dy.shape
-            db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C))
+            db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C), out=_grad_out(ctx.bias_param))
         return dx, dw, db, None
 
 

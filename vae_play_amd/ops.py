@@ -116,7 +116,15 @@ def conv5_scatter(small: torch.Tensor, w_p1: torch.Tensor, stride: int) -> torch
     return out
 
 
-def conv5_wgrad(big: torch.Tensor, small: torch.Tensor, stride: int) -> torch.Tensor:
+def _out(out: Optional[torch.Tensor], shape, device) -> torch.Tensor:
+    """``out`` (a caller-owned fp32 buffer of that shape, e.g. a parameter's slice of the optimiser's gradient arena) or a new tensor"""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    assert tuple(out.shape) == tuple(shape) and out.is_contiguous() and out.dtype == torch.float32
+    return out
+
+
+def conv5_wgrad(big: torch.Tensor, small: torch.Tensor, stride: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW[Cs][Cb][5][5] in the reference layout."""
     assert _is_nhwc(big) and _is_nhwc(small)
     B, Cb, Hb, Wb = big.shape
@@ -124,7 +132,7 @@ def conv5_wgrad(big: torch.Tensor, small: torch.Tensor, stride: int) -> torch.Te
     assert Hb == Hs * stride and Wb == Ws * stride and small.shape[0] == B
     nbytes = _lib.load().vp_conv5_wgrad_workspace_bytes(B, Hs, Ws, Cb, Cs, stride)
     ws = _ws(nbytes, big)
-    dw = torch.empty((Cs, Cb, 5, 5), dtype=torch.float32, device=big.device)
+    dw = _out(out, (Cs, Cb, 5, 5), big.device)
     _lib.call("vp_conv5_wgrad_f32", _p(big), _p(small), _p(dw), B, Hs, Ws, Cb, Cs, stride, _p(ws), ws.numel() * 4, _stream())
     return dw
 
@@ -157,19 +165,19 @@ def linear_dgrad(dy: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     return gemm(dy, N, 1, W, 1, K, M, K, N, 1)
 
 
-def linear_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW[N,K] = dy[M,N]^T x[M,K]."""
     dy, x = dy.contiguous(), x.contiguous()
     M, N = dy.shape
     K = x.shape[1]
-    return gemm(dy, 1, N, x, 1, K, N, K, M, 2)
+    return gemm(dy, 1, N, x, 1, K, N, K, M, 2, out=out)
 
 
-def colsum(x2d: torch.Tensor) -> torch.Tensor:
+def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     R, C = x2d.shape
     assert x2d.is_contiguous()
     ws = _ws(_lib.load().vp_colsum_workspace_bytes(R, C), x2d)
-    out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
+    out = _out(out, (C,), x2d.device)
     _lib.call("vp_colsum_f32", _p(x2d), _p(out), R, C, _p(ws), ws.numel() * 4, _stream())
     return out
 
@@ -207,12 +215,13 @@ def bn_act_fwd(x, mean, rstd, gamma, beta, act: int, slope: float = 0.0, want_sp
     return y
 
 
-def bn_act_bwd(x, dy, mean, rstd, gamma, beta, act: int, slope: float, batch_stats: bool, need_affine_grads: bool = True):
+def bn_act_bwd(x, dy, mean, rstd, gamma, beta, act: int, slope: float, batch_stats: bool, need_affine_grads: bool = True,
+               out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None):
     R, C = _rc(x)
     assert _same_layout(dy, x)
     dx = torch.empty_like(x)
-    dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if need_affine_grads else None
-    dbeta = torch.empty_like(dgamma) if need_affine_grads else None
+    dgamma = _out(out_dgamma, (C,), x.device) if need_affine_grads else None
+    dbeta = _out(out_dbeta, (C,), x.device) if need_affine_grads else None
     ws = _ws(_lib.load().vp_bn_workspace_bytes(R, C), x)
     _lib.call("vp_bn_act_bwd_f32", _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta),
               R, C, act, float(slope), int(batch_stats), _p(ws), ws.numel() * 4, _stream())
@@ -503,12 +512,12 @@ def conv5_scatter_bf16x3(small_split, shape_small, w_p1_split, Cb: int, stride: 
     return out
 
 
-def conv5_wgrad_bf16x3(big_split, shape_big, small_split, shape_small, stride: int):
+def conv5_wgrad_bf16x3(big_split, shape_big, small_split, shape_small, stride: int, out: Optional[torch.Tensor] = None):
     B, Cb, Hb, Wb = shape_big
     _, Cs, Hs, Ws = shape_small
     nbytes = _lib.load().vp_conv5_wgrad_bf16x3_workspace_bytes(B, Hs, Ws, Cb, Cs, stride)
     ws = torch.empty(max(4, (nbytes + 3) // 4), dtype=torch.float32, device=big_split.device)
-    dw = torch.empty((Cs, Cb, 5, 5), dtype=torch.float32, device=big_split.device)
+    dw = _out(out, (Cs, Cb, 5, 5), big_split.device)
     _lib.call("vp_conv5_wgrad_bf16x3", _pv(big_split), _pv(small_split), _p(dw), B, Hs, Ws, Cb, Cs, stride, _p(ws), ws.numel() * 4, _stream())
     return dw
 
@@ -578,13 +587,13 @@ def conv_scatter(small, w_p1, ks: int, stride: int, Hb: int, Wb: int):
     return out
 
 
-def conv_wgrad(big, small, ks: int, stride: int):
+def conv_wgrad(big, small, ks: int, stride: int, out: Optional[torch.Tensor] = None):
     assert _is_nhwc(big) and _is_nhwc(small)
     B, Cb, Hb, Wb = big.shape
     _, Cs, Hs, Ws = small.shape
     nbytes = _lib.load().vp_conv_wgrad_workspace_bytes(B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride)
     ws = _ws(nbytes, big)
-    dw = torch.empty((Cs, Cb, ks, ks), dtype=torch.float32, device=big.device)
+    dw = _out(out, (Cs, Cb, ks, ks), big.device)
     _lib.call("vp_conv_wgrad_f32", _p(big), _p(small), _p(dw), B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride, _p(ws), ws.numel() * 4, _stream())
     return dw
 
@@ -616,12 +625,12 @@ def conv_scatter_bf16x3(small_split, shape_small, w_p1_split, Cb: int, ks: int, 
     return out
 
 
-def conv_wgrad_bf16x3(big_split, shape_big, small_split, shape_small, ks: int, stride: int):
+def conv_wgrad_bf16x3(big_split, shape_big, small_split, shape_small, ks: int, stride: int, out: Optional[torch.Tensor] = None):
     B, Cb, Hb, Wb = shape_big
     _, Cs, Hs, Ws = shape_small
     nbytes = _lib.load().vp_conv_wgrad_bf16x3_workspace_bytes(B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride)
     ws = _ws(nbytes, big_split)
-    dw = torch.empty((Cs, Cb, ks, ks), dtype=torch.float32, device=big_split.device)
+    dw = _out(out, (Cs, Cb, ks, ks), big_split.device)
     _lib.call("vp_conv_wgrad_bf16x3", _pv(big_split), _pv(small_split), _p(dw), B, Hs, Ws, Hb, Wb, Cb, Cs, ks, stride, _p(ws),
               ws.numel() * 4, _stream())
     return dw

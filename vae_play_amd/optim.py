@@ -21,6 +21,10 @@ from . import ops
 _ALIGN = 64  # floats (256 B)
 
 
+def _clear_pending(p) -> None:
+    p._vp_pending = False
+
+
 class FlatArena:
     """Owns flat parameter / gradient buffers and re-points the nn.Parameters at views of them."""
 
@@ -50,8 +54,26 @@ class FlatArena:
                 p.data = view
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
                 p._vp_arena = self
+                p._vp_off = o
+                p._vp_pending = False
+                # functional._grad_out hands this slice to ONE backward function per pass; autograd's accumulation re-arms it
+                p.register_post_accumulate_grad_hook(_clear_pending)
 
-    def zero_grad(self) -> None:
+    def grad_view(self, p) -> torch.Tensor:
+        """``p``'s slice of the flat gradient buffer, shaped like ``p``"""
+        return self.flat_grad[p._vp_off:p._vp_off + p.numel()].view_as(p)
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """set_to_none: drop the ``.grad`` views instead of zero-filling the arena (like ``module.zero_grad()``): the next backward
+        pass then writes each parameter's gradient straight into its arena slice (functional._grad_out) and ``gather_grads`` zeroes
+        the slices of parameters that received none."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+                p._vp_pending = False
+            for p in self.foreign:
+                p.grad = None
+            return
         self.flat_grad.zero_()
         for p in self.foreign:
             if p.grad is not None:
@@ -85,7 +107,7 @@ class _FlatOptimizer:
         self.step_count = 0
 
     def zero_grad(self, set_to_none: bool = False) -> None:
-        self.arena.zero_grad()
+        self.arena.zero_grad(set_to_none)
 
     # ---- checkpointing: plain tensors / numbers only (vae_play_amd/checkpoint.py) -------------------------
     _STATE = ()

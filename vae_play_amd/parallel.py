@@ -89,6 +89,7 @@ class DataParallelStep:
         self.optimizer.zero_grad()
 
     def step(self) -> None:
+        self.optimizer.arena.gather_grads()      # gradients that live outside the arena (module.zero_grad()) come home first
         allreduce_flat_grads(self.optimizer.flat_grad, self.group)
         self.optimizer.step()
 
