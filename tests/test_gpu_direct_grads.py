@@ -79,3 +79,46 @@ def test_gradient_lands_in_the_arena_without_a_copy():
         assert p.grad is not None and p.grad.data_ptr() == base + 4 * o, "autograd adopted something other than the arena slice"
         assert torch.isfinite(p.grad).all()
         assert not p._vp_pending
+
+
+def test_packed_weight_cache_follows_optimiser_and_torch_updates():
+    """functional._packed: a conv weight is re-packed when (and only when) its value changed -- by a flat-arena optimiser step
+    (kernels behind torch's version counter) or by a torch in-place op."""
+    import vae_play_amd as V
+    from vae_play_amd import functional as Fh, optim
+    torch.manual_seed(0)
+    vae = V.VAE(32, 16, 3).to(DEV)
+    opt = optim.Adam(vae.parameters(), lr=1e-2)
+    Fh.set_conv_precision("bf16x3")
+    try:
+        x = torch.rand(4, 3, 32, 32, device=DEV)
+        eps = torch.randn(4, 16, device=DEV)
+
+        def run():
+            xt, mu, lv = vae(x, eps=eps)
+            return xt.detach().clone()
+        a = run()
+        b = run()                              # served from the cache
+        assert torch.equal(a, b)
+        opt.zero_grad()
+        xt, mu, lv = vae(x, eps=eps)
+        V.vae_loss(x, xt, mu, lv)[0].backward()
+        opt.step()                             # weights change behind torch's back
+        c = run()
+        assert not torch.equal(a, c), "stale packed weights after an optimiser step"
+        old = Fh._PACK_CACHE_ON
+        Fh._PACK_CACHE_ON = False
+        try:
+            assert torch.equal(c, run()), "cached and freshly packed weights disagree"
+        finally:
+            Fh._PACK_CACHE_ON = old
+        with torch.no_grad():
+            vae.decoder.conv[0].conv.weight.mul_(0.5)      # torch in-place update: the version counter moves
+        d = run()
+        Fh._PACK_CACHE_ON = False
+        try:
+            assert torch.equal(d, run())
+        finally:
+            Fh._PACK_CACHE_ON = old
+    finally:
+        Fh.set_conv_precision("f32")

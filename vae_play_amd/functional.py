@@ -14,6 +14,7 @@ Reference ops replaced (relative to the reference checkout):
 from __future__ import annotations
 
 import os
+import weakref
 
 from typing import Optional
 
@@ -73,6 +74,32 @@ def _grad_out(param) -> Optional[torch.Tensor]:
 _DIRECT_GRADS = os.environ.get("VP_DIRECT_GRADS", "1") != "0"
 
 
+_PACKED = {}     # (id(weight), layout) -> (weight, weight._version, optimiser epoch, packed tensor)
+
+
+def _packed(fn, weight, want_p1: bool):
+    """``fn(weight, want_p0, want_p1)`` (an ops.pack_* re-layout of a conv weight) through a cache: a layer that runs several times
+    per step -- the VAE-GAN's decoder decodes z and z_p, its discriminator sees both -- packs each layout once per weight VALUE.
+    Valid while neither torch (``_version``) nor a flat-arena optimiser (ops.PARAM_EPOCH: its kernels update the weights behind
+    torch's back) has changed the parameter; only leaf parameters are cached."""
+    if not (isinstance(weight, torch.nn.Parameter) and _PACK_CACHE_ON):
+        r = fn(weight, not want_p1, want_p1)
+        return r[1] if want_p1 else r[0]
+    key = (id(weight), fn.__name__, want_p1, _PRECISION)
+    hit = _PACKED.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == ops.PARAM_EPOCH[0]:
+        return hit[3]
+    r = fn(weight, not want_p1, want_p1)
+    t = r[1] if want_p1 else r[0]
+    if len(_PACKED) > 4096:          # ids of dead parameters (models built and dropped, e.g. by a test session)
+        _PACKED.clear()
+    _PACKED[key] = (weakref.ref(weight), weight._version, ops.PARAM_EPOCH[0], t)
+    return t
+
+
+_PACK_CACHE_ON = os.environ.get("VP_PACK_CACHE", "1") != "0"
+
+
 def _use16(weight) -> bool:
     return _PRECISION == "bf16x3" and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
 
@@ -103,12 +130,12 @@ class _Conv5(Function):
             return y
         if ctx.x16:
             xs = _split_of(x)
-            p0, _ = ops.pack_w5_split(weight, True, False)
+            p0 = _packed(ops.pack_w5_split, weight, False)
             y = ops.conv5_gather_bf16x3(xs, x.shape, p0, weight.shape[0], bias, stride, act)
             ctx.xshape = tuple(x.shape)
             x = xs          # the split copy is what the weight gradient reads
         else:
-            p0, _ = ops.pack_w5(weight, True, False)
+            p0 = _packed(ops.pack_w5, weight, False)
             # the image side of the final conv (64 -> 1 | 3 channels, models/networks.py:100-103) on the matrix cores: the edge
             # kernels of the fused step (taps in the MFMA columns / rows, a kernel row per k-step) instead of the VALU kernels
             ctx.edge = (_PRECISION == "bf16x3" and stride == 1 and weight.shape[1] == 64 and weight.shape[0] in (1, 3)
@@ -149,7 +176,7 @@ class _Conv5(Function):
         if ctx.x16:
             dys = ops.split_f32(dy)
             if ctx.needs_input_grad[0]:
-                _, p1 = ops.pack_w5_split(weight, False, True)
+                p1 = _packed(ops.pack_w5_split, weight, True)
                 dx = ops.conv5_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.stride)
             if ctx.needs_input_grad[1]:
                 dw = ops.conv5_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.stride, out=_grad_out(weight))
@@ -179,7 +206,7 @@ class _Conv5(Function):
                     _, p1 = ops.pack_w5_split(wpad, False, True)
                     dx = ops.conv5_scatter_bf16x3(ops.split_f32(dy), dy.shape, p1, 8, ctx.stride)[:, :Cb]
                 else:
-                    _, p1 = ops.pack_w5(weight, False, True)
+                    p1 = _packed(ops.pack_w5, weight, True)
                     dx = ops.conv5_scatter(dy, p1, ctx.stride)
             if ctx.needs_input_grad[1]:
                 B, Cs, H, W = dy.shape
@@ -209,12 +236,12 @@ class _ConvT5(Function):
         ctx.x16 = _use16(weight)
         if ctx.x16:
             xs = _split_of(x)
-            _, p1 = ops.pack_w5_split(weight, False, True)
+            p1 = _packed(ops.pack_w5_split, weight, True)
             y = ops.conv5_scatter_bf16x3(xs, x.shape, p1, weight.shape[1], stride)
             ctx.xshape = tuple(x.shape)
             x = xs
         else:
-            _, p1 = ops.pack_w5(weight, False, True)
+            p1 = _packed(ops.pack_w5, weight, True)
             y = ops.conv5_scatter(x, p1, stride)
         ctx.stride = stride
         ctx.save_for_backward(x, weight)
@@ -228,13 +255,13 @@ class _ConvT5(Function):
         if ctx.x16:
             dys = ops.split_f32(dy)
             if ctx.needs_input_grad[0]:
-                p0, _ = ops.pack_w5_split(weight, True, False)
+                p0 = _packed(ops.pack_w5_split, weight, False)
                 dx = ops.conv5_gather_bf16x3(dys, dy.shape, p0, weight.shape[0], None, ctx.stride, ACT_NONE)
             if ctx.needs_input_grad[1]:
                 dw = ops.conv5_wgrad_bf16x3(dys, tuple(dy.shape), x, ctx.xshape, ctx.stride, out=_grad_out(weight))
             return dx, dw, None
         if ctx.needs_input_grad[0]:
-            p0, _ = ops.pack_w5(weight, True, False)
+            p0 = _packed(ops.pack_w5, weight, False)
             dx = ops.conv5_gather(dy, p0, None, ctx.stride, ACT_NONE)
         if ctx.needs_input_grad[1]:
             dw = ops.conv5_wgrad(dy, x, ctx.stride, out=_grad_out(weight))
@@ -359,11 +386,11 @@ class _ConvK(Function):
             return y[:, :Co] if Cop != Co else y
         if ctx.x16:                     # split-bf16 kernels (set_conv_precision("bf16x3"), channel counts multiples of 8)
             xs = _split_of(x)
-            p0, _ = ops.pack_w_split(weight, True, False)
+            p0 = _packed(ops.pack_w_split, weight, False)
             y = ops.conv_gather_bf16x3(xs, x.shape, p0, weight.shape[0], bias, ks, stride, ACT_NONE)
             x = xs
         else:
-            p0, _ = ops.pack_w(weight, True, False)
+            p0 = _packed(ops.pack_w, weight, False)
             y = ops.conv_gather(x, p0, bias, ks, stride, ACT_NONE)
         ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
         ctx.bias_param = bias
@@ -393,13 +420,13 @@ class _ConvK(Function):
         if ctx.x16:
             dys = ops.split_f32(dy)
             if ctx.needs_input_grad[0]:
-                _, p1 = ops.pack_w_split(weight, False, True)
+                p1 = _packed(ops.pack_w_split, weight, True)
                 dx = ops.conv_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.ks, ctx.stride, ctx.xshape[2], ctx.xshape[3])
             if ctx.needs_input_grad[1]:
                 dw = ops.conv_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.ks, ctx.stride, out=_grad_out(weight))
         else:
             if ctx.needs_input_grad[0]:
-                _, p1 = ops.pack_w(weight, False, True)
+                p1 = _packed(ops.pack_w, weight, True)
                 dx = ops.conv_scatter(dy, p1, ctx.ks, ctx.stride, x.shape[2], x.shape[3])
             if ctx.needs_input_grad[1]:
                 dw = ops.conv_wgrad(x, dy, ctx.ks, ctx.stride, out=_grad_out(weight))

@@ -442,6 +442,8 @@ def empty_split(n: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty((2, n), dtype=torch.int16, device=like.device)
 
 
+PARAM_EPOCH = [0]        # bumped by every flat-arena optimiser step: the arena kernels change weights without touching torch's version counters
+
 SPLIT_BF16, SPLIT_F16 = 0, 1     # VP_SPLIT_* of include/vaeplay_hip.h: bf16 pair ("bf16x3" kernels) | fp16 pair ("f16x2" kernels)
 
 

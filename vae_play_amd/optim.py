@@ -190,6 +190,7 @@ class Adam(_FlatOptimizer):
         """Update arena elements [lo, hi) (offsets are multiples of 64 floats) with the current step count; the
         gradients must already be in the arena (the fused engine writes them there)."""
         if hi > lo:
+            ops.PARAM_EPOCH[0] += 1
             a = self.arena
             ops.adam_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
                           self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale)
@@ -207,6 +208,7 @@ class Adam(_FlatOptimizer):
     @torch.no_grad()
     def step(self, outer: bool = False) -> None:
         self.step_count += 1
+        ops.PARAM_EPOCH[0] += 1
         a = self.arena
         if a.numel:
             a.gather_grads()
@@ -255,6 +257,7 @@ class RMSprop(_FlatOptimizer):
     @torch.no_grad()
     def step_range(self, lo: int, hi: int) -> None:
         if hi > lo:
+            ops.PARAM_EPOCH[0] += 1
             a = self.arena
             ops.rmsprop_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.square_avg[lo:hi], self.lr, self.alpha, self.eps,
                              self.grad_scale)
@@ -262,6 +265,7 @@ class RMSprop(_FlatOptimizer):
     @torch.no_grad()
     def step(self) -> None:
         self.step_count += 1
+        ops.PARAM_EPOCH[0] += 1
         a = self.arena
         if a.numel:
             a.gather_grads()

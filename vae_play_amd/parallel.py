@@ -69,6 +69,8 @@ def allgather_rows(out_all: torch.Tensor, local: torch.Tensor, group=None, async
 def broadcast_flat_params(flat_param: torch.Tensor, src: int = 0, group=None) -> None:
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_param, src=src, group=group)
+        from . import ops
+        ops.PARAM_EPOCH[0] += 1          # the parameters changed under their views: packed-weight caches are stale
 
 
 class DataParallelStep:
