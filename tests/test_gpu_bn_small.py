@@ -41,3 +41,17 @@ def test_bn_small_is_bit_identical_to_the_three_launch_path(R, C):
         assert torch.equal(a, b), what
     with pytest.raises(_lib.VaePlayHipError):
         _lib.call("vp_bn_small_fwd_f32", P(x), 65, C, 1e-5, 0.9, P(gamma), P(beta), P(m2), P(r2), None, None, P(y2), 1, 0.0, ops._stream())
+
+
+@pytest.mark.parametrize("R,C", [(786432, 32), (5000, 8), (1000, 60), (70, 24), (65, 36), (300, 3), (200, 128)])
+def test_colsum_variants_against_fp64(R, C):
+    """vp_colsum_f32 (bias gradients): every dispatch branch -- the 16-B row form for narrow C % 4 == 0, the row-lane form, the wide
+    form -- against an fp64 column sum."""
+    from vae_play_amd import ops
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) + 0.1).cuda()
+    got = ops.colsum(x)
+    ref = x.double().sum(dim=0)
+    scale = x.double().abs().sum(dim=0)
+    assert ((got.double() - ref).abs() / scale).max().item() <= 2e-6
+    assert torch.equal(got, ops.colsum(x)), "column sums must be deterministic"
