@@ -24,3 +24,8 @@ VP_SIDE_WGRAD=0 VP_XCD_MAP=2 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FE
 echo "traffic done"
 find $O -name "*.csv" | head -40
 du -sh $O
+# afterwards, in the repository (the CSVs come back under gpurun_out/prof):
+#   python profiles/make_summary.py  gpurun_out/prof/ks_serial/t_kernel_stats.csv 222 "<title>" > profiles/rNN_x_summary_serial.md   (also ks_conc, ks_x2_serial)
+#   python profiles/make_mfma_busy.py gpurun_out/prof/mfma/t_counter_collection.csv > profiles/rNN_x_mfma_busy.md                     (also mfma_x2)
+#   python profiles/make_traffic.py  gpurun_out/prof/fetch/t_counter_collection.csv gpurun_out/prof/write/t_counter_collection.csv 5 profiles/rNN_x_traffic.json > profiles/rNN_x_traffic.md
+#   python profiles/make_roofline.py gpurun_out/prof 222 5 > profiles/rNN_x_roofline_table.md
