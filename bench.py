@@ -14,9 +14,10 @@ operand, ~1e-5 parity with the fp32 reference); `--precision f32` runs every con
 (v_mfma_f32_32x32x2_f32).  Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel family of the
 step (the 5x5 implicit-GEMM convolutions, MFMA-bound): algorithmic FLOPs of its launches / their summed HIP-event
 durations inside the timed region.  `variants` (one GPU only, measured after the headline's timed region, same
-protocol): the exact-f32 mode, per-GPU batches 64 / 128 / 256 and BASELINE config 2 (64x64x3, z=64, batch 128).
-`comm` says what the gradient exchange ran on.  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py = the
-reference's torch-CPU algorithm) on this box's host cores: 2 warm-ups, best of 5, all cores of the affinity mask.
+protocol): the exact-f32 mode, the f16x2 mode (fp16 pairs: three MFMAs per product forward, two backward), per-GPU batches
+64 / 128 / 256 and BASELINE config 2 (64x64x3, z=64, batch 128).  `comm` says what the gradient exchange ran on.
+`cpu_baseline` times the CPU oracle (oracle/ref_cpu.py = the reference's torch-CPU algorithm) on this box's host cores: 2 warm-ups,
+best of 5, threads = min(affinity mask, cgroup CPU quota).
 """
 import argparse
 import json

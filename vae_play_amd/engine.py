@@ -6,8 +6,10 @@ The plan is built once for a (model, batch size) pair:
   * every parameter gradient is written exactly once, directly into the optimiser's flat gradient
     arena (no zero_grad pass, no accumulate pass) -- the arena is then all-reduced once (RCCL) and
     consumed by the fused optimiser kernel;
-  * the launch list is replayable and hipGraph-capturable (``capture()``), which removes the
-    launch-bound gaps between the ~150 small kernels of a step.
+  * the launch list is replayable and hipGraph-capturable (``capture()``); the eager form stays the default because it runs
+    the weight gradients on a side stream underneath the main chain, which a replayed graph serialises (DESIGN.md section 5);
+  * three arithmetic modes (``precision=``): exact fp32, split-bf16 (three MFMAs per product) and fp16 pairs with two MFMAs per
+    product on the backward layers.
 
 It drives the same C-ABI entry points as the autograd modules and must produce identical
 gradients (tests/test_gpu_engine.py).  Reference path replaced: the loop body train_BE.py:54-64
