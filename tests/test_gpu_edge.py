@@ -83,3 +83,28 @@ def test_final_conv_input_gradient_rowk_matches_torch(B, H, W, nin):
     # the exact-fp32 scatter kernel computes the same gradient
     _, p1 = ops.pack_w5(w.cuda(), False, True)
     assert_close(out.cpu(), ops.conv5_scatter(dld, p1, 1).cpu(), 3e-5, "rows-in-K vs exact-f32 kernel")
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 1, 32), (1, 24, 40, 3, 32), (2, 33, 17, 1, 64), (3, 128, 128, 1, 32)])
+def test_first_conv_stride1_input_gradient_matches_torch(B, H, W, cin, cout):
+    """Input gradient of Conv2d(1|3 -> 32|64, k5, s1, p2) (the VAE-GAN discriminator's first layer) through the autograd op in
+    bf16x3 mode: the tap-in-N kernel with 32 / 64 gathered channels and flipped taps, against torch on the CPU."""
+    from vae_play_amd import functional as Fh
+    g = torch.Generator().manual_seed(17 + H + cout)
+    x = torch.rand(B, cin, H, W, generator=g)
+    w = (torch.rand(cout, cin, 5, 5, generator=g) - 0.5) * 0.2
+    b = torch.rand(cout, generator=g) - 0.5
+    gy = torch.randn(B, cout, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, b, padding=2).backward(gy)
+    Fh.set_conv_precision("bf16x3")
+    try:
+        xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        y = Fh.conv5x5(xd, wd, bd, stride=1)
+        y.backward(gy.cuda().contiguous(memory_format=torch.channels_last))
+    finally:
+        Fh.set_conv_precision("f32")
+    assert_close(xd.grad.cpu(), xr.grad, 3e-5, "first conv input gradient")
+    for sl in ((..., 0, slice(None)), (..., H - 1, slice(None)), (..., slice(None), 0), (..., slice(None), W - 1)):
+        assert_close(xd.grad.cpu()[sl], xr.grad[sl], 1e-4, "border")

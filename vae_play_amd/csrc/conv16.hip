@@ -450,7 +450,7 @@ int vp_conv5_smallout_bf16x3(const float* big, const float* w_p0, const float* b
   VP_REQUIRE(big && w_p0 && small_out && B > 0 && H > 0 && W > 0, "vp_conv5_smallout_bf16x3: bad arguments");
   VP_REQUIRE(((uintptr_t)big & 15) == 0 && ((uintptr_t)w_p0 & 15) == 0, "vp_conv5_smallout_bf16x3: operands must be 16-byte aligned");
   const ConvGeom g = make_geom(B, H, W, Csmall, Cbig, 1);
-  VP_REQUIRE(tapn_gather_applicable(g, act), "vp_conv5_smallout_bf16x3: needs 64 input channels, 1 or 3 outputs, act none|sigmoid");
+  VP_REQUIRE(tapn_gather_applicable(g, act), "vp_conv5_smallout_bf16x3: needs 64 or 32 input channels, 1 or 3 outputs, act none|sigmoid");
   return tapn_gather_launch(big, w_p0, bias, small_out, g, act, (hipStream_t)stream);
 }
 

@@ -363,11 +363,13 @@ __device__ __forceinline__ void split8(const vp_f32x4& a, const vp_f32x4& b, bf1
 // 8 waves per workgroup (two per SIMD: the patch loads, the MFMAs and the P stores of different waves overlap -- with four
 // waves they ran back to back: 32 + 40 + 22 us of a 102-us kernel), workgroups persistent over the tile list so that the
 // weight fragments are loaded and split once per workgroup.
-template <int NOUT>
+template <int NOUT, int C>
 __global__ void __launch_bounds__(512, 2) conv5s1_tapn_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               int H, int W, int tiles_x, int tiles_per_img, int ntiles, int act) {
-  constexpr int C = 64, T = 16, HALO = T + 4, NPIX = HALO * HALO;     // 400 patch pixels
+  static_assert(C == 64 || C == 32, "64 input channels (the VAE's final conv) or 32 (input gradient of a 1|3 -> 32 first conv)");
+  constexpr int T = 16, HALO = T + 4, NPIX = HALO * HALO;            // 400 patch pixels
+  constexpr int NS = C / 16, NRAW = C / 8, HC = C / 2;                // MFMA k-steps, 16-B loads per lane, channels per lane half
   constexpr int NCOL = 25 * NOUT, NT = (NCOL + 31) / 32;               // 75 -> 3 column tiles, 25 -> 1
   constexpr int PITCH = 32 * NT + 1;                                   // odd word pitch
   constexpr int MT = (NPIX + 31) / 32;                                 // 13 row tiles
@@ -376,16 +378,16 @@ __global__ void __launch_bounds__(512, 2) conv5s1_tapn_kernel(const float* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
 
-  // B fragments: row (32 jt + li) of the [NCOL][C] weight view, channels 32*lh + 8*s .. +7 for MFMA k-step s
-  bf16x8_e bh[NT][4], bl[NT][4];
+  // B fragments: row (32 jt + li) of the [NCOL][C] weight view, channels HC*lh + 8*s .. +7 for MFMA k-step s
+  bf16x8_e bh[NT][NS], bl[NT][NS];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     const int row = 32 * jt + li;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NS; ++s) {
       vp_f32x4 a = zero4(), c = zero4();
       if (row < NCOL) {
-        const float* q = w + (size_t)row * C + 32 * lh + 8 * s;
+        const float* q = w + (size_t)row * C + HC * lh + 8 * s;
         a = ld4(q);
         c = ld4(q + 4);
       }
@@ -394,18 +396,18 @@ __global__ void __launch_bounds__(512, 2) conv5s1_tapn_kernel(const float* __res
   }
 
   // patch row tile t of output tile `tile`: 32 pixels x 64 channels, one 128-B half line per lane
-  auto load_tile = [&](int tile, int t, vp_f32x4 (&raw)[8]) {
+  auto load_tile = [&](int tile, int t, vp_f32x4 (&raw)[NRAW]) {
     const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
     const int h0 = (rem / tiles_x) * T, w0 = (rem % tiles_x) * T;
     const int pi = 32 * t + li;
     const int py = pi / HALO, px = pi - py * HALO;
     const int gh = h0 + py - 2, gw = w0 + px - 2;
     const bool ok = pi < NPIX && gh >= 0 && gh < H && gw >= 0 && gw < W;
-    const float* q = in + ((size_t)(b * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * C + 32 * lh;
+    const float* q = in + ((size_t)(b * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * C + HC * lh;
 #pragma unroll
-    for (int v = 0; v < 8; ++v) raw[v] = ok ? ld4(q + 4 * v) : zero4();
+    for (int v = 0; v < NRAW; ++v) raw[v] = ok ? ld4(q + 4 * v) : zero4();
   };
-  vp_f32x4 cur[8], nxt[8];
+  vp_f32x4 cur[NRAW], nxt[NRAW];
   if ((int)blockIdx.x < ntiles && wave < MT) load_tile(blockIdx.x, wave, cur);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(512, 2) conv5s1_tapn_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NS; ++s) {
         bf16x8_e ah, al;
         split8(cur[2 * s], cur[2 * s + 1], ah, al);
 #pragma unroll
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(512, 2) conv5s1_tapn_kernel(const float* __res
         }
       if (more) {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) cur[v] = nxt[v];
+        for (int v = 0; v < NRAW; ++v) cur[v] = nxt[v];
       }
     }
     // the first patch rows of the workgroup's NEXT tile are requested before the shifted sum: their latency hides under it
@@ -481,13 +483,15 @@ bool narrow_gather_applicable(const ConvGeom& g, int act) {
 
 // split-bf16 arithmetic on the matrix cores (conv5s1_tapn_kernel): 64 input channels, 1 or 3 outputs
 bool tapn_gather_applicable(const ConvGeom& g, int act) {
-  return narrow_gather_applicable(g, act) && g.Cb == 64;
+  return narrow_gather_applicable(g, act) && (g.Cb == 64 || g.Cb == 32);
 }
 int tapn_gather_launch(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g, int act, hipStream_t s) {
   const int tiles_x = (g.Ws + 15) / 16, tiles_per_img = tiles_x * ((g.Hs + 15) / 16), ntiles = tiles_per_img * g.B;
   const dim3 pgrid((unsigned)(ntiles < 256 ? ntiles : 256));          // one persistent workgroup per CU
-  if (g.Cs == 3) hipLaunchKernelGGL((conv5s1_tapn_kernel<3>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act);
-  else hipLaunchKernelGGL((conv5s1_tapn_kernel<1>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act);
+#define VP_TAPN(NO, CC) hipLaunchKernelGGL((conv5s1_tapn_kernel<NO, CC>), pgrid, dim3(512), 0, s, big, w_p0, bias, out, g.Hs, g.Ws, tiles_x, tiles_per_img, ntiles, act)
+  if (g.Cb == 64) { if (g.Cs == 3) VP_TAPN(3, 64); else VP_TAPN(1, 64); }
+  else { if (g.Cs == 3) VP_TAPN(3, 32); else VP_TAPN(1, 32); }
+#undef VP_TAPN
   return check_launch("conv5s1_tapn");
 }
 

@@ -196,6 +196,15 @@ class _Conv5(Function):
                     dyp = torch.zeros((B, H, W, 8), dtype=torch.float32, device=dy.device)
                     dyp[..., :Cs] = dy.permute(0, 2, 3, 1)
                     dx = ops.conv5_scatter_bf16x3(ops.split_f32(dyp), (B, 8, H, W), ops.pack_w5_p1_split_padded(weight, 8), Cb, 1)
+                elif (_PRECISION == "bf16x3" and Cb in (1, 3) and Cs in (32, 64) and ctx.stride == 1
+                      and os.environ.get("VP_EDGE_AUTOGRAD", "1") != "0"):
+                    # input gradient of a stride-1 first conv (the VAE-GAN discriminator's 1 -> 32, models/networks.py:160-163:
+                    # its input is the decoder's output): dx[p] = sum_{tap, co} dy[p - tap + 2][co] W[co][ci][tap] is the
+                    # "many channels -> 1 | 3" correlation of the tap-in-N kernel with the taps flipped
+                    B, _, H, W = dy.shape
+                    wf = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cb, 25, Cs).contiguous()      # [ci][tap'][co]
+                    dx = ops.empty_cl(B, Cb, H, W, dy)
+                    _lib.call("vp_conv5_smallout_bf16x3", ops._p(dy), ops._p(wf), None, ops._p(dx), B, H, W, Cs, Cb, ACT_NONE, ops._stream())
                 elif _PRECISION == "bf16x3" and Cb < 8 and Cs % 8 == 0 and os.environ.get("VP_NARROW_DGRAD16", "1") != "0":
                     # the image side of a FIRST conv whose input gradient is needed (the VAE-GAN discriminator's, models/
                     # networks.py:160-163: its input is the decoder's output): zero-pad the weight's input channels to 8,
