@@ -145,6 +145,11 @@ int vp_conv5_scatter_stats_bf16x3(const void* small_split, const void* w_p1_spli
  * layout, split-bf16 arithmetic on the matrix cores with one kernel row of taps (5*C contiguous floats of `small`) per MFMA k-step. */
 int vp_conv5_smallin_dgrad_bf16x3(const float* small, const float* w_ref, float* big_out, int B, int H, int W, int Csmall, int Cbig,
                                   vp_stream stream);
+/* Forward pass of a stride-1 first conv on a 1- or 3-channel image (nn.Conv2d(C, 32 | 64, k5, s1, p2) + ReLU, the VAE-GAN
+ * discriminator's first layer, models/networks.py:160-163): big_out[b,h,w,cf] = act(bias[cf] + sum small[b,h+r-2,w+q-2,n] * w_ref[cf][n][r][q]),
+ * fp32 NHWC operands, reference weight layout, act none | relu; the same rows-in-K kernel as vp_conv5_smallin_dgrad_bf16x3. */
+int vp_conv5_smallin_fwd_bf16x3(const float* small, const float* w_ref, const float* bias, float* big_out, int B, int H, int W, int Csmall,
+                                int Cbig, int act, vp_stream stream);
 /* Input-gradient convolution + the reduction pass of the BatchNorm backward it feeds (autograd of nn.BatchNorm2d + F.relu,
  * models/networks.py:28-29,44-45): the launch's output small_out / big_out is dy of a BatchNorm(+ReLU) layer whose convolution
  * output is bn_x (same layout); the epilogue emits per-workgroup {sum g, sum g*xhat}, g = dy * act'(gamma*xhat + beta), and one

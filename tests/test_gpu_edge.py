@@ -108,3 +108,33 @@ def test_first_conv_stride1_input_gradient_matches_torch(B, H, W, cin, cout):
     assert_close(xd.grad.cpu(), xr.grad, 3e-5, "first conv input gradient")
     for sl in ((..., 0, slice(None)), (..., H - 1, slice(None)), (..., slice(None), 0), (..., slice(None), W - 1)):
         assert_close(xd.grad.cpu()[sl], xr.grad[sl], 1e-4, "border")
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,act", [(2, 16, 16, 1, 32, "relu"), (1, 24, 40, 3, 32, None), (2, 33, 17, 1, 64, "relu"),
+                                               (3, 128, 128, 1, 32, "relu")])
+def test_first_conv_stride1_forward_matches_torch(B, H, W, cin, cout, act):
+    """Forward pass of Conv2d(1|3 -> 32|64, k5, s1, p2) + bias (+ ReLU) through the autograd op in bf16x3 mode (the rows-in-K kernel's
+    forward form) and its gradients, against torch on the CPU."""
+    from vae_play_amd import functional as Fh
+    g = torch.Generator().manual_seed(19 + H + cout)
+    x = torch.rand(B, cin, H, W, generator=g)
+    w = (torch.rand(cout, cin, 5, 5, generator=g) - 0.5) * 0.2
+    b = torch.rand(cout, generator=g) - 0.5
+    gy = torch.randn(B, cout, H, W, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=2)
+    yr = torch.relu(yr) if act == "relu" else yr
+    yr.backward(gy)
+    Fh.set_conv_precision("bf16x3")
+    try:
+        xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        assert Fh.first_conv_s1_edge(wd, 1)
+        y = Fh.conv5x5(xd, wd, bd, stride=1, act=act)
+        y.backward(gy.cuda().contiguous(memory_format=torch.channels_last))
+    finally:
+        Fh.set_conv_precision("f32")
+    assert_close(y.detach().cpu(), yr.detach(), 3e-5, "first conv forward")
+    assert_close(xd.grad.cpu(), xr.grad, 3e-5, "input gradient")
+    assert_close(wd.grad.cpu(), wr.grad, 3e-5, "weight gradient")
+    assert_close(bd.grad.cpu(), br.grad, 3e-5, "bias gradient")

@@ -73,6 +73,7 @@ SIGNATURES = {
     "vp_conv5_stats_f16_workspace_bytes": (c_size_t, [c_int] * 7),
     "vp_conv5_gather_stats_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_conv5_scatter_stats_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_conv5_smallin_fwd_bf16x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_smallin_dgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_gather_bnbwd_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [P, P, P, P, P, c_int, P, P, P, P, c_size_t, P]),
     "vp_conv5_scatter_bnbwd_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [P, P, P, P, P, c_int, P, P, P, P, c_size_t, P]),

@@ -188,18 +188,23 @@ int tapm_wgrad_launch(const float* big_f32, const float* small_f32, float* dw_re
 //     and parked in LDS in fragment order; workgroups are persistent over the tile list, two per CU, and request the next tile's
 //     patch before the current tile's MFMAs and stores;
 //   * 30 MFMAs (5 k-steps x 2 column tiles x 3 products) per 32 pixels x 64 channels, then 8 KB of stores.
-template <int NIN>
+// FWD = false: the input gradient above (taps flipped, weights [NIN][CF][5][5]);  FWD = true: the FORWARD pass of a stride-1 conv with
+// 1 | 3 input channels, big_out[b,h,w,cf] = act(bias[cf] + sum_{r,q,n} small[b, h+r-2, w+q-2, n] * W[cf][n][r][q]) (weights
+// [CF][NIN][5][5], act none | relu): the VAE-GAN discriminator's first layer, models/networks.py:160-163.  CF = 64 | 32 wide channels.
+template <int NIN, int CF, bool FWD>
 __global__ void __launch_bounds__(512, 2) dgrad_rowk_kernel(const float* __restrict__ dlogit, const float* __restrict__ w,
                                                             float* __restrict__ out, int H, int W, int tiles_x, int tiles_per_img,
-                                                            int ntiles) {
-  constexpr int CF = 64, TR = 8, TC = 32, PR = TR + 4, PC = (TC + 4) * NIN + 8;     // patch: 12 rows x (36 pixels x NIN floats, + slack)
+                                                            int ntiles, const float* __restrict__ bias = nullptr, int act = ACT_NONE) {
+  static_assert(CF == 64 || CF == 32, "wide channel count");
+  constexpr int NJT = CF / 32;
+  constexpr int TR = 8, TC = 32, PR = TR + 4, PC = (TC + 4) * NIN + 8;     // patch: 12 rows x (36 pixels x NIN floats, + slack)
   constexpr int KROW = 5 * NIN;                                                     // useful k per kernel row (<= 15)
   __shared__ float patch[PR * PC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
   typedef float f32x16_l __attribute__((ext_vector_type(16)));
-  __shared__ __attribute__((aligned(16))) bf16x8_l bfr[5 * 2 * 2 * 64];                                // weight fragments [r][jt][hi|lo][lane]
+  __shared__ __attribute__((aligned(16))) bf16x8_l bfr[5 * NJT * 2 * 64];                              // weight fragments [r][jt][hi|lo][lane]
   auto split8 = [](const float (&x)[8], bf16x8_l& h, bf16x8_l& l) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -213,17 +218,18 @@ __global__ void __launch_bounds__(512, 2) dgrad_rowk_kernel(const float* __restr
   if (wave < 5) {
     const int r = wave;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+    for (int jt = 0; jt < NJT; ++jt) {
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int k = 8 * lh + j, d = k / NIN, n = k - d * NIN;
-        x[j] = k < KROW ? w[(((size_t)n * CF + 32 * jt + li) * 5 + r) * 5 + (4 - d)] : 0.f;
+        const int k = 8 * lh + j, d = k / NIN, n = k - d * NIN, cf = 32 * jt + li;
+        const size_t wi = FWD ? (((size_t)cf * NIN + n) * 5 + r) * 5 + d : (((size_t)n * CF + cf) * 5 + r) * 5 + (4 - d);
+        x[j] = k < KROW ? w[wi] : 0.f;
       }
       bf16x8_l h8, l8;
       split8(x, h8, l8);
-      bfr[((r * 2 + jt) * 2 + 0) * 64 + lane] = h8;
-      bfr[((r * 2 + jt) * 2 + 1) * 64 + lane] = l8;
+      bfr[((r * NJT + jt) * 2 + 0) * 64 + lane] = h8;
+      bfr[((r * NJT + jt) * 2 + 1) * 64 + lane] = l8;
     }
   }
   // the patch of a tile: PR x (TC+4) x NIN floats, <= 3 per thread; the NEXT tile's values are requested before this tile's MFMAs and
@@ -255,23 +261,24 @@ __global__ void __launch_bounds__(512, 2) dgrad_rowk_kernel(const float* __restr
     if (tid < PR * 8) patch[(tid >> 3) * PC + (TC + 4) * NIN + (tid & 7)] = 0.f;      // the slack a k >= KROW read may touch
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) load_patch(tile + (int)gridDim.x);
-    f32x16_l acc[2];
+    f32x16_l acc[NJT];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
       // output pixel (row = wave, column li): gradient row h - r + 2 = patch row wave + 4 - r, columns w-2 .. w+2 = patch pixel li ..
-      const float* q = &patch[(wave + 4 - r) * PC + li * NIN + 8 * lh];
+      // (forward: input row h + r - 2 = patch row wave + r)
+      const float* q = &patch[(FWD ? wave + r : wave + 4 - r) * PC + li * NIN + 8 * lh];
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = (8 * lh + j < KROW) ? q[j] : 0.f;
       bf16x8_l ah, al;
       split8(x, ah, al);
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
-        const bf16x8_l bh = bfr[((r * 2 + jt) * 2 + 0) * 64 + lane], bl = bfr[((r * 2 + jt) * 2 + 1) * 64 + lane];
+      for (int jt = 0; jt < NJT; ++jt) {
+        const bf16x8_l bh = bfr[((r * NJT + jt) * 2 + 0) * 64 + lane], bl = bfr[((r * NJT + jt) * 2 + 1) * 64 + lane];
         acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[jt], 0, 0, 0);
         acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[jt], 0, 0, 0);
         acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[jt], 0, 0, 0);
@@ -280,12 +287,16 @@ __global__ void __launch_bounds__(512, 2) dgrad_rowk_kernel(const float* __restr
     const int h = h0 + wave;
     if (h < H) {
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
+      for (int jt = 0; jt < NJT; ++jt) {
+        const float bv = (FWD && bias) ? bias[32 * jt + li] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int ww = w0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (ww < W) out[((size_t)(b * H + h) * W + ww) * CF + 32 * jt + li] = acc[jt][e];
+          float v = acc[jt][e] + bv;
+          if (FWD && act == ACT_RELU) v = v > 0.f ? v : 0.f;
+          if (ww < W) out[((size_t)(b * H + h) * W + ww) * CF + 32 * jt + li] = v;
         }
+      }
     }
   }
 }
@@ -323,12 +334,27 @@ int vp_conv5_smallin_dgrad_bf16x3(const float* small, const float* w_ref, float*
   const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8, ntiles = B * tiles_x * tiles_y;
   const int grid = ntiles < 512 ? ntiles : 512;                 // persistent: two workgroups (8 waves each) per CU
   if (Csmall == 3)
-    hipLaunchKernelGGL((dgrad_rowk_kernel<3>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
-                       tiles_x * tiles_y, ntiles);
+    hipLaunchKernelGGL((dgrad_rowk_kernel<3, 64, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
+                       tiles_x * tiles_y, ntiles, (const float*)nullptr, 0);
   else
-    hipLaunchKernelGGL((dgrad_rowk_kernel<1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
-                       tiles_x * tiles_y, ntiles);
+    hipLaunchKernelGGL((dgrad_rowk_kernel<1, 64, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
+                       tiles_x * tiles_y, ntiles, (const float*)nullptr, 0);
   return check_launch("vp_conv5_smallin_dgrad_bf16x3");
+}
+
+int vp_conv5_smallin_fwd_bf16x3(const float* small, const float* w_ref, const float* bias, float* big_out, int B, int H, int W, int Csmall,
+                                int Cbig, int act, vp_stream stream) {
+  VP_REQUIRE(small && w_ref && big_out && B > 0 && H > 0 && W > 0, "vp_conv5_smallin_fwd_bf16x3: bad arguments");
+  VP_REQUIRE((Cbig == 32 || Cbig == 64) && (Csmall == 1 || Csmall == 3), "vp_conv5_smallin_fwd_bf16x3: needs 1 or 3 input and 32 or 64 output channels");
+  VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_RELU, "vp_conv5_smallin_fwd_bf16x3: activation none|relu");
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8, ntiles = B * tiles_x * tiles_y;
+  const int grid = ntiles < 512 ? ntiles : 512;
+#define VP_ROWK_FWD(NI, CFF) hipLaunchKernelGGL((dgrad_rowk_kernel<NI, CFF, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, \
+                                                H, W, tiles_x, tiles_x * tiles_y, ntiles, bias, act)
+  if (Cbig == 64) { if (Csmall == 3) VP_ROWK_FWD(3, 64); else VP_ROWK_FWD(1, 64); }
+  else { if (Csmall == 3) VP_ROWK_FWD(3, 32); else VP_ROWK_FWD(1, 32); }
+#undef VP_ROWK_FWD
+  return check_launch("vp_conv5_smallin_fwd_bf16x3");
 }
 
 }

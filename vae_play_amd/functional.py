@@ -100,6 +100,12 @@ def _packed(fn, weight, want_p1: bool):
 _PACK_CACHE_ON = os.environ.get("VP_PACK_CACHE", "1") != "0"
 
 
+def first_conv_s1_edge(weight, stride: int) -> bool:
+    """Does conv5x5(x, weight, bias, stride) run on the rows-in-K forward kernel (which takes a ReLU in its epilogue)?"""
+    return (_PRECISION == "bf16x3" and stride == 1 and weight.shape[1] in (1, 3) and weight.shape[0] in (32, 64)
+            and os.environ.get("VP_EDGE_AUTOGRAD", "1") != "0")
+
+
 def _use16(weight) -> bool:
     return _PRECISION == "bf16x3" and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
 
@@ -127,6 +133,18 @@ class _Conv5(Function):
             ctx.cols = (KC, B, H, W)
             ctx.stride, ctx.act, ctx.has_bias = stride, act, False
             ctx.save_for_backward(xcol, weight, None)
+            return y
+        if first_conv_s1_edge(weight, stride) and act in (ACT_NONE, ops.ACT_RELU):
+            # stride-1 first conv on a 1- / 3-channel image (the VAE-GAN discriminator's, models/networks.py:160-163) with bias and
+            # ReLU in the epilogue: a kernel row of taps per MFMA k-step (csrc/edge.hip, the rows-in-K kernel's forward form)
+            B, _, H, W = x.shape
+            y = ops.empty_cl(B, Cs, H, W, x)
+            _lib.call("vp_conv5_smallin_fwd_bf16x3", ops._p(x), ops._p(weight.contiguous()), ops._p(bias), ops._p(y), B, H, W, Cb, Cs, act,
+                      ops._stream())
+            ctx.x16 = False
+            ctx.stride, ctx.act, ctx.has_bias = stride, act, bias is not None
+            ctx.bias_param = bias
+            ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
             return y
         if ctx.x16:
             xs = _split_of(x)

@@ -221,7 +221,10 @@ class _ReluConv(nn.Sequential):
     parameter-free ReLU.  The conv runs on the MFMA kernel, bias in its epilogue, ReLU as one elementwise pass."""
 
     def forward(self, x):
-        return F_hip.activation(self[0](x), "relu")
+        conv = self[0]
+        if F_hip.first_conv_s1_edge(conv.weight, conv.stride):       # bias + ReLU in the convolution's epilogue
+            return conv(x, act="relu")
+        return F_hip.activation(conv(x), "relu")
 
 
 class Discriminator(nn.Module):
