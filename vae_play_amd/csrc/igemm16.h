@@ -296,9 +296,14 @@ using ProbT16KX = ProbT16T<false, 1>;
 using ProbT16H = ProbT16T<true, 2>;
 using ProbT16KH = ProbT16T<false, 2>;
 
-// W family on split planes: slab[split][tap][cs][cb]; both operands pixel-major (KM)
-template <bool K5, int MODE_ = 0>
+// W family on split planes: slab[split][tap][cs][cb]; both operands pixel-major (KM).
+// PAIR (narrow big side, Cb = 32 | 64): one workgroup contracts TWO taps, the columns [0, Cb) of its virtual N = 2*Cb tile belong to
+// tap 2*pair and [Cb, 2*Cb) to tap 2*pair + 1 (same `small` rows, two shifted `big` pixels per staged k row): a 32-channel layer
+// fills a 64-column tile, a 64-channel layer the 128-column one, instead of leaving half of the MFMA columns (or of the A-fragment
+// reuse) unused.  13 pairs cover the 25 taps; the odd half of the last pair is masked.
+template <bool K5, int MODE_ = 0, bool PAIR_ = false>
 struct ProbW16T {
+  static constexpr bool PAIR = PAIR_;
   static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split)
   static constexpr bool X2 = MODE_ == 1, F16 = MODE_ != 0;
   float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
@@ -312,9 +317,14 @@ struct ProbW16T {
   const u16* big; size_t big_plane;
   const u16* small; size_t small_plane;
   float* slab; const void* zero; ConvGeom g; int M, N, K; int nsplit, k_per_split;
-  struct ZCtx { int k_begin, k_end, rr, qq, tap, split; };
+  struct ZCtx { int k_begin, k_end, rr, qq, tap, split, rr2, qq2; };
   VP_HD void z_setup(int zi, ZCtx& z) const {
     z.tap = zi / nsplit; z.split = zi - z.tap * nsplit;
+    if (PAIR) {                      // zi / nsplit = the pair: taps 2*pair and 2*pair + 1 (the latter may be 25: masked)
+      const int t2 = 2 * z.tap + 1;
+      z.tap = 2 * z.tap;
+      z.rr2 = t2 / ks(); z.qq2 = t2 - z.rr2 * ks();
+    } else { z.rr2 = z.qq2 = 0; }
     z.rr = z.tap / ks(); z.qq = z.tap - z.rr * ks();
     z.k_begin = z.split * k_per_split;
     int e = z.k_begin + k_per_split; z.k_end = e < K ? e : K;
@@ -326,8 +336,11 @@ struct ProbW16T {
   VP_HD u32x4_t b_load_km(int k, int n, int plane, const ZCtx& z) const {   // big[shifted pixel][n..n+7]
     int b = (int)g.dHW.div((uint32_t)k); int rem = k - b * (g.Hs * g.Ws);
     int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
-    int h = g.stride * hs - pad() + z.rr, w_ = g.stride * ws - pad() + z.qq;
-    const bool ok = k < z.k_end && n < N && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+    int rr = z.rr, qq = z.qq;
+    bool tap_ok = true;
+    if (PAIR && n >= g.Cb) { rr = z.rr2; qq = z.qq2; n -= g.Cb; tap_ok = z.tap + 1 < nt(); }
+    int h = g.stride * hs - pad() + rr, w_ = g.stride * ws - pad() + qq;
+    const bool ok = tap_ok && k < z.k_end && n < (PAIR ? g.Cb : N) && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
     return ld16(ok ? big + plane * big_plane + ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb + n : reinterpret_cast<const u16*>(zero));
   }
   // FAST row-level form (tile fully inside M x N): element offset of channel 0 of pixel k
@@ -342,17 +355,32 @@ struct ProbW16T {
     off = ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb;
     return k < z.k_end && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
   }
+  // PAIR: the second tap's pixel of the same k row
+  VP_HD bool b_base_km2(int k, const ZCtx& z, size_t& off) const {
+    int b = (int)g.dHW.div((uint32_t)k); int rem = k - b * (g.Hs * g.Ws);
+    int hs = (int)g.dW.div((uint32_t)rem), ws = rem - hs * g.Ws;
+    int h = g.stride * hs - pad() + z.rr2, w_ = g.stride * ws - pad() + z.qq2;
+    off = ((size_t)(b * g.Hb + h) * g.Wb + w_) * g.Cb;
+    return z.tap + 1 < nt() && k < z.k_end && h >= 0 && h < g.Hb && w_ >= 0 && w_ < g.Wb;
+  }
   VP_HD const u16* a_ptr() const { return small; }
   VP_HD size_t a_plane() const { return small_plane; }
   VP_HD const u16* b_ptr() const { return big; }
   VP_HD size_t b_plane() const { return big_plane; }
   VP_HD void store(int m, int n, float v, const ZCtx& z) const {
     if (m >= M || n >= N) return;
+    if (PAIR) {                      // N = 2*Cb virtual columns -> (tap, real column); the slab keeps its [split][tap][cs][cb] layout
+      const int second = n >= g.Cb ? 1 : 0;
+      if (z.tap + second >= nt()) return;
+      slab[(((size_t)z.split * nt() + z.tap + second) * M + m) * g.Cb + (n - second * g.Cb)] = F16 ? v * alpha : v;
+      return;
+    }
     slab[(((size_t)z.split * nt() + z.tap) * M + m) * N + n] = F16 ? v * alpha : v;
   }
 };
 using ProbW16 = ProbW16T<true>;
 using ProbW16K = ProbW16T<false>;
+using ProbW16P = ProbW16T<true, 0, true>;     // tap pairs (plain 5x5 layers with 32 or 64 big channels)
 using ProbW16X = ProbW16T<true, 1>;
 using ProbW16KX = ProbW16T<false, 1>;
 
@@ -644,7 +672,21 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
     } else {
       constexpr int V = BN / 8, TP = 256 / BKT;
       const int kr = tid / TP, c0 = tid % TP;
-      if constexpr (FAST) {
+      if constexpr (FAST && P::PAIR) {
+        // two taps per workgroup: chunk columns [0, V/2) of a plane come from tap A's pixel, [V/2, V) from tap B's (n0 = 0: one tile)
+        size_t offa, offb;
+        const bool oka = p.b_base_km(k0 + kr, z, offa), okb = p.b_base_km2(k0 + kr, z, offb);
+        const u16* const zp = reinterpret_cast<const u16*>(p.zero);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          if (P::X2 && TP * i >= V) continue;
+          const int ch = c0 + TP * i, pl = ch / V, cv = ch % V;
+          const bool second = cv >= V / 2;
+          const bool ok = second ? okb : oka;
+          const u16* src = ok ? p.b_ptr() + (pl ? p.b_plane() : 0) + (second ? offb : offa) + (cv - (second ? V / 2 : 0)) * 8 : zp;
+          sb[i] = ld16(src);
+        }
+      } else if constexpr (FAST) {
         size_t off;
         const bool ok = p.b_base_km(k0 + kr, z, off);
         const u16* b0 = ok ? p.b_ptr() + off + n0 : reinterpret_cast<const u16*>(p.zero);
