@@ -310,6 +310,15 @@ int vp_half_sqdiff_rowsum_f32(const float* a, const float* b, float* out, int R,
 /* da = g*(a-b), db = -da (either may be NULL); g has one value per row (g_per_row=1) or per element (0) */
 int vp_half_sqdiff_bwd_f32(const float* a, const float* b, const float* g, float* da, float* db, int R, int n_per_row,
                            int g_per_row, vp_stream stream);
+/* ---- VAE-GAN loss heads for the fused VAE-GAN step (VaeGan.loss, models/networks.py:275-279; weights of train.py:63-66) ---- */
+/* logit [3B] = discriminator scores before F.sigmoid (models/networks.py:190) of (original | reconstructed | sampled);
+ * p_out = sigmoid(logit); sums[0..2] = sum_b -log(p + 1e-3) over the originals and sum_b -log(1 - p + 1e-3) over the reconstructed /
+ * sampled rows (:275-277); dlogit = coef * d(sums[0] + sums[1] + sums[2]) / dlogit.  Any output may be NULL. */
+int vp_gan_head_f32(const float* logit, int B, float coef, float* p_out, float* sums, float* dlogit, vp_stream stream);
+/* loss[0] = scale * F.smooth_l1_loss(targets, cat(a, b, dim=1), reduction="sum") (models/networks.py:279, beta = 1) with targets
+ * [B][n1 + n2], a [B][n1], b [B][n2] (DirectDecoder's two heads, models/networks.py:144-147); da, db = d loss / d a, b. */
+int vp_smooth_l1_cat_f32(const float* targets, const float* a, const float* b, int B, int n1, int n2, float scale, float* loss,
+                         float* da, float* db, vp_stream stream);
 /* out[0] = sum x */
 int vp_sum_f32(const float* x, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream);
 /* loss tail of the composed VAE step (F.binary_cross_entropy(x_tilde, x, reduction='sum') + the KL of

@@ -1,5 +1,6 @@
-"""Throughput of the VAE-GAN training step on the drop-in modules: VaeGan forward, VaeGan.loss,
-the five losses of train.py:61-66, five backward passes over one graph, four flat-arena RMSprop steps.
+"""Throughput of the VAE-GAN training step: VaeGan forward, VaeGan.loss, the five losses of train.py:61-66,
+their backward passes, four flat-arena RMSprop steps -- as the pre-planned launch list of engine_gan.FusedVAEGANStep (--path fused,
+default) or on the drop-in modules with loss.backward() (--path autograd).
 usage: python tools/bench_vaegan.py [--img 128] [--z 128] [--batch 16] [--steps 10] [--cpu-steps 1]
 Prints one JSON line; `cpu_baseline` is the oracle restatement on this host's CPU (test infrastructure)."""
 import argparse
@@ -86,6 +87,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3")
     ap.add_argument("--five-pass", action="store_true", help="the reference's five backward(retain_graph=True) calls instead of one")
+    ap.add_argument("--path", choices=["fused", "autograd"], default="fused",
+                    help="fused: engine_gan.FusedVAEGANStep (pre-planned launch list, bf16x3); autograd: the drop-in modules + loss.backward()")
     a = ap.parse_args()
     import vae_play_amd as V
     from vae_play_amd import optim, parallel
@@ -105,14 +108,26 @@ def main():
     targets = torch.rand(a.batch, 3, generator=g).to(dev)
     eps = torch.randn(a.batch, a.z, generator=g).to(dev)
     z_p = torch.randn(a.batch, a.z, generator=g).to(dev)
+    fused = None
+    if a.path == "fused":
+        if a.precision != "bf16x3":
+            raise SystemExit("--path fused runs the bf16x3 plan")
+        from vae_play_amd.engine_gan import FusedVAEGANStep
+        fused = FusedVAEGANStep(net, opts, a.batch, a.img, lambda_mse=1e-6)
+
+        def do_step(net, opts, x, targets, eps, z_p, V, lam, one_pass=True, dp=None):      # same call shape as the autograd step
+            fused.step(x, targets, eps, z_p)        # (several ranks: it all-reduces the four arenas itself)
+            return fused.kl
+    else:
+        do_step = step
     for _ in range(a.warmup):
-        step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass, dp)
+        do_step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass, dp)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass, dp)
+        loss = do_step(net, opts, x, targets, eps, z_p, V, 1e-6, not a.five_pass, dp)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -126,12 +141,16 @@ def main():
            "ms_per_step": round(dt * 1e3, 3), "config": {"workload": f"VaeGan {a.img}x{a.img}x1 z={a.z} batch {a.batch} per rank",
                                                          "path": f"autograd modules on HIP kernels ({a.precision} convolutions)",
                                                          "backward": "five passes (train.py:69-73)" if a.five_pass else "one pass over the summed losses"},
-           "loss_encoder": float(loss.detach())}
+           "loss_encoder": fused.losses()["loss_encoder"] if fused is not None else float(loss.detach())}
+    if fused is not None:
+        out["config"]["path"] = "engine_gan.FusedVAEGANStep: pre-planned launch list, weight gradients on a side stream (bf16x3 convolutions)"
+        out["config"]["launches_per_step"] = len(fused._fwd.calls) + len(fused._fwd_disc.calls) + len(fused._bwd.calls)
     gf = step_gflop_per_image(a.img, a.z)
     ach = world * a.batch / dt * gf / 1e3 / world          # algorithmic TFLOP/s per GPU over the whole step
     peak = 2500.0 if a.precision == "bf16x3" else 157.3
     out["dtype"] = a.precision
-    out["roofline"] = {"bound": "mfma", "kernel": "whole step (autograd front end; per-kernel table: profiles/*_vaegan_summary.md)",
+    out["roofline"] = {"bound": "mfma", "kernel": ("whole step (fused plan; per-kernel table: profiles/*_vaegan_fused_summary*.md)" if fused is not None else
+                                                   "whole step (autograd front end; per-kernel table: profiles/*_vaegan_summary.md)"),
                        "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                        "mfma_issue_frac": round(ach * (3 if a.precision == "bf16x3" else 1) / peak, 4), "traffic": None,
                        "step_gflop_per_image": round(gf, 3)}

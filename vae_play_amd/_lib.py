@@ -128,6 +128,8 @@ SIGNATURES = {
     "vp_half_sqdiff_f32": (c_int, [P, P, P, c_size_t, P]),
     "vp_half_sqdiff_rowsum_f32": (c_int, [P, P, P, c_int, c_int, P]),
     "vp_half_sqdiff_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "vp_gan_head_f32": (c_int, [P, c_int, c_float, P, P, P, P]),
+    "vp_smooth_l1_cat_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P, P, P]),
     "vp_adam_f32": (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "vp_adam_outer_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "vp_rmsprop_f32": (c_int, [P, P, P, c_size_t, c_float, c_float, c_float, c_float, P]),

@@ -190,6 +190,56 @@ __global__ void half_sqdiff_bwd_kernel(const float* __restrict__ a, const float*
   }
 }
 
+// ---- VAE-GAN loss heads (VaeGan.loss, models/networks.py:275-279; train.py:63-66) ----
+// GAN head over the (3B) discriminator logits of (original | reconstructed | sampled): p = sigmoid(logit),
+// bce_original = -log(p + 1e-3), bce_predicted / bce_sampled = -log(1 - p + 1e-3); sums[0..2] = their sums over the B rows
+// of each group, dlogit = coef * d(sum of the three)/dlogit.  One workgroup (3B is a few dozen rows).
+__global__ void __launch_bounds__(256) gan_head_kernel(const float* __restrict__ logit, int B, float coef, float* __restrict__ p_out,
+                                                       float* __restrict__ sums, float* __restrict__ dlogit) {
+  __shared__ float sh[3][4];
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < 3 * B; i += 256) {
+    const float y = 1.f / (1.f + __expf(-logit[i]));
+    const int grp = i / B;
+    float u, dldy;
+    if (grp == 0) { u = y + 1e-3f; dldy = -1.f / u; }
+    else          { u = (1.f - y) + 1e-3f; dldy = 1.f / u; }
+    acc[grp] += -__logf(u);
+    if (p_out) p_out[i] = y;
+    if (dlogit) dlogit[i] = coef * dldy * y * (1.f - y);
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float w = wave_sum(acc[g]);
+    if ((threadIdx.x & 63) == 0) sh[g][threadIdx.x >> 6] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && sums) sums[threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// F.smooth_l1_loss(targets, cat(a, b), reduction="sum") * scale (models/networks.py:279: beta = 1) over B rows of n1 + n2 columns;
+// a [B][n1] and b [B][n2] are the two heads of DirectDecoder before the cat; da / db = d loss / d a, b.  One workgroup.
+__global__ void __launch_bounds__(256) smooth_l1_cat_kernel(const float* __restrict__ t, const float* __restrict__ a, const float* __restrict__ b,
+                                                            int B, int n1, int n2, float scale, float* __restrict__ loss,
+                                                            float* __restrict__ da, float* __restrict__ db) {
+  __shared__ float sh[4];
+  const int n = n1 + n2;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < B * n; i += 256) {
+    const int r = i / n, c = i - r * n;
+    const float pv = c < n1 ? a[r * n1 + c] : b[r * n2 + (c - n1)];
+    const float d = t[i] - pv, ad = fabsf(d);
+    acc += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+    const float g = -scale * fminf(fmaxf(d, -1.f), 1.f);
+    if (c < n1) { if (da) da[r * n1 + c] = g; }
+    else if (db) db[r * n2 + (c - n1)] = g;
+  }
+  const float w = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) loss[0] = scale * ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
 // ---- segmentation loss of train_BE.py:58-59: w * BCEWithLogits(x, t) (mean) + dice(sigmoid(x), t) (tools/ops.py:12-19)
 // sums[b] = { sum bce_i, sum p_i t_i, sum p_i, sum t_i } over the n elements of sample b, p = sigmoid(x).
 // Two stages (chunk partials in fp32 lanes -> fp64 tree, then a fixed-order fp64 sum over chunks): bit-reproducible.
@@ -820,6 +870,19 @@ int vp_half_sqdiff_bwd_f32(const float* a, const float* b, const float* g, float
   hipLaunchKernelGGL(half_sqdiff_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a, b, g, da, db, total,
                      n_per_row, g_per_row ? 1 : 0);
   return check_launch("vp_half_sqdiff_bwd_f32");
+}
+
+int vp_gan_head_f32(const float* logit, int B, float coef, float* p_out, float* sums, float* dlogit, vp_stream stream) {
+  VP_REQUIRE(logit && B > 0 && (p_out || sums || dlogit), "vp_gan_head_f32: bad arguments");
+  hipLaunchKernelGGL(gan_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logit, B, coef, p_out, sums, dlogit);
+  return check_launch("vp_gan_head_f32");
+}
+
+int vp_smooth_l1_cat_f32(const float* targets, const float* a, const float* b, int B, int n1, int n2, float scale, float* loss,
+                         float* da, float* db, vp_stream stream) {
+  VP_REQUIRE(targets && a && B > 0 && n1 > 0 && n2 >= 0 && (b || n2 == 0) && (loss || da || db), "vp_smooth_l1_cat_f32: bad arguments");
+  hipLaunchKernelGGL(smooth_l1_cat_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, targets, a, b, B, n1, n2, scale, loss, da, db);
+  return check_launch("vp_smooth_l1_cat_f32");
 }
 
 int vp_bce_bwd_f32(const float* p, const float* t, const float* gptr, float gscale, float* dp, size_t n, vp_stream stream) {
