@@ -14,6 +14,9 @@ CASES = [  # (B, Hs, Cb, Cs, stride): channel counts multiples of 8
     (2, 4, 8, 8, 2), (2, 8, 64, 128, 2), (3, 5, 16, 24, 2), (8, 32, 32, 512, 2), (6, 64, 16, 64, 2),
     (2, 16, 128, 64, 2), (1, 8, 256, 256, 2), (2, 12, 64, 64, 1), (4, 16, 512, 256, 2),
     (32, 8, 256, 256, 2), (2, 8, 192, 320, 2), (4, 64, 32, 128, 2), (2, 16, 32, 96, 2), (3, 20, 24, 40, 1),
+    # weight gradient on tap pairs (Cb = 32 with Cs % 64 == 0, Cb = 64 with Cs % 128 == 0): the VAE-GAN discriminator's 32 -> 64
+    # block, stride 1 (padding on all sides), a K shorter than one K-tile per split
+    (3, 16, 32, 64, 2), (2, 10, 64, 256, 1), (1, 4, 32, 64, 2), (2, 3, 64, 128, 1),
 ]
 
 

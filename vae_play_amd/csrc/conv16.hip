@@ -294,13 +294,14 @@ int vp_pack_w_split(const float* w_ref, void* p0_split, void* p1_split, int Csma
 }
 
 size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
-  ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride);
-  return wgrad_slab_floats(g, wgrad_nsplit(g)) * sizeof(float);
+  return vp_conv_wgrad_bf16x3_workspace_bytes(B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride);
 }
 
 size_t vp_conv_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride) {
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
-  return wgrad_slab_floats(g, wgrad_nsplit(g)) * sizeof(float);
+  int ns = wgrad_nsplit(g);
+  if (wgrad_pair_applicable(g, ks == 5 && Hb == Hs * stride && Wb == Ws * stride)) ns = wgrad_pair_nsplit(g, ns);   // tap pairs split twice as deep
+  return wgrad_slab_floats(g, ns) * sizeof(float);
 }
 
 int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,

@@ -665,10 +665,10 @@ class FusedVAEStep:
         lib = _lib.load()
         B, S, C = self.B, self.S, self.C
         n = lib.vp_conv5_wgrad_workspace_bytes(B, S, S, Cf, C, 1)
-        for blk, Cin, Cout, Hs, *_ in enc_rec:
-            n = max(n, lib.vp_conv5_wgrad_workspace_bytes(B, Hs, Hs, Cin, Cout, 2))
+        for blk, Cin, Cout, Hs, *_ in enc_rec:        # (the split-bf16 query may ask for more: tap pairs split the pixels deeper)
+            n = max(n, lib.vp_conv5_wgrad_workspace_bytes(B, Hs, Hs, Cin, Cout, 2), lib.vp_conv5_wgrad_bf16x3_workspace_bytes(B, Hs, Hs, Cin, Cout, 2))
         for blk, Cin, Cout, Hs, *_ in dec_rec:
-            n = max(n, lib.vp_conv5_wgrad_workspace_bytes(B, Hs, Hs, Cout, Cin, 2))
+            n = max(n, lib.vp_conv5_wgrad_workspace_bytes(B, Hs, Hs, Cout, Cin, 2), lib.vp_conv5_wgrad_bf16x3_workspace_bytes(B, Hs, Hs, Cout, Cin, 2))
         return n
 
     # ---- execution ---------------------------------------------------------------------------
