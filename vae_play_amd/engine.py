@@ -507,13 +507,16 @@ class FusedVAEStep:
             bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         cur, other = gA, gB
         # split gradient (output of BN backward) for the 16-bit kernels, two buffers used alternately
-        gS2 = [self._sbuf("g.S0", big), self._sbuf("g.S1", big)] if x3 else [None, None]
+        # (VP_GS_BUFS = number of buffers in the rotation, default 2: with one buffer per layer the main stream never waits for a
+        # side-stream weight gradient before rewriting a buffer -- one cross-queue dependency less per layer)
+        n_gs = max(2, int(os.environ.get("VP_GS_BUFS", "2")))
+        gS2 = [self._sbuf(f"g.S{j}", big) for j in range(n_gs)] if x3 else [None] * n_gs
         self._grad_planes = gS2 if x2 else []
-        gs_last = [None, None]      # side event of the weight gradient that last read each buffer
+        gs_last = [None] * n_gs     # side event of the weight gradient that last read each buffer
         gs_turn = [0]
 
         def next_gs(plan):
-            k = gs_turn[0] % 2
+            k = gs_turn[0] % n_gs
             gs_turn[0] += 1
             if gs_last[k] is not None:
                 plan.wait_side(gs_last[k])

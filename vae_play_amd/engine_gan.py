@@ -398,12 +398,13 @@ class FusedVAEGANStep:
         hA, hB = self._buf("g.hA", big_v), self._buf("g.hB", big_v)        # decoder / encoder phases
         big_s = max([n3 * r[3] * r[3] * r[2] for r in disc_rec] + [B * 4 * r[3] * r[3] * r[2] for r in dec1["blocks"]]
                     + [B * r[3] * r[3] * r[2] for r in enc_rec])
-        gS2 = [self._sbuf("g.S0", big_s), self._sbuf("g.S1", big_s)]
-        gs_last = [None, None]
+        n_gs = max(2, int(os.environ.get("VP_GS_BUFS", "2")))     # rotation depth of the gradient planes (engine.py)
+        gS2 = [self._sbuf(f"g.S{j}", big_s) for j in range(n_gs)]
+        gs_last = [None] * n_gs
         gs_turn = [0]
 
         def next_gs():
-            k = gs_turn[0] % 2
+            k = gs_turn[0] % n_gs
             gs_turn[0] += 1
             if gs_last[k] is not None:
                 bwd.wait_side(gs_last[k])
