@@ -171,6 +171,13 @@ size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, in
 int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref,
                           int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
                           void* ws, size_t ws_bytes, vp_stream stream);
+/* Second half of every weight-gradient entry point above (the gradient of nn.Conv2d / nn.ConvTranspose2d weights,
+ * models/networks.py:14,38): the K-split launch leaves slab[split][tap][Csmall][Cbig]; this sums the splits in a fixed order
+ * (even splits, odd splits, their sum: bit-reproducible, no atomics) and writes the reference layout dw[Csmall][Cbig][tap].
+ * variant: -1 = what the library dispatches, 0 = 4-B loads, 1 = 16-B loads (needs Csmall * Cbig % 64 == 0 and 16-B aligned
+ * pointers); every variant returns the same bits.  Exposed for callers that split K themselves and for the parity tests. */
+int vp_wgrad_slab_reduce_f32(const float* slab, float* dw_ref, int Csmall, int Cbig, int nsplit, int ntaps, int variant,
+                             vp_stream stream);
 /* producers of split tensors fused into the elementwise passes (y / dx / out may be NULL when only
  * the split copy is wanted) */
 /* nn.BatchNorm1d(momentum=0.9) + activation behind nn.Linear (models/networks.py:66-67,89-90), forward and backward, for at most

@@ -80,6 +80,7 @@ SIGNATURES = {
     "vp_bn_act_bwd_apply_split_f32": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_int, P]),
     "vp_conv5_wgrad_bf16x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vp_conv5_wgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "vp_wgrad_slab_reduce_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_bn_small_fwd_f32": (c_int, [P, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P, c_int, c_float, P]),
     "vp_bn_small_bwd_f32": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_int, P]),
     "vp_bn_act_fwd_split_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),

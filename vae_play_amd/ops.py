@@ -173,6 +173,16 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] 
     return gemm(dy, 1, N, x, 1, K, N, K, M, 2, out=out)
 
 
+def wgrad_slab_reduce(slab: torch.Tensor, Cs: int, Cb: int, nt: int, variant: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """slab[nsplit][nt][Cs][Cb] (the K-split weight-gradient launches' workspace) -> dw[Cs][Cb][nt], splits summed in a fixed order."""
+    nsplit = slab.numel() // (nt * Cs * Cb)
+    assert slab.is_contiguous() and slab.numel() == nsplit * nt * Cs * Cb
+    if out is None:
+        out = torch.empty((Cs, Cb, nt), device=slab.device, dtype=torch.float32)
+    _lib.call("vp_wgrad_slab_reduce_f32", _p(slab), _p(out), Cs, Cb, nsplit, nt, variant, _stream())
+    return out
+
+
 def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     R, C = x2d.shape
     assert x2d.is_contiguous()
