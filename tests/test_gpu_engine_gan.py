@@ -49,7 +49,8 @@ def _autograd_step(net, opts, x, targets, eps, z_p, lam):
     return {k: v.detach().clone() for k, v in outs.items()}, {k: float(v) for k, v in losses.items()}
 
 
-@pytest.mark.parametrize("S,z,B,fuse_stats", [(32, 16, 4, "0"), (64, 32, 4, "0"), (32, 16, 8, "1")])
+# (128, 128, 16) = tools/bench_vaegan.py's shape (BASELINE config 4 per rank): every tile / split / tap-pair branch of the benchmark runs here
+@pytest.mark.parametrize("S,z,B,fuse_stats", [(32, 16, 4, "0"), (64, 32, 4, "0"), (32, 16, 8, "1"), (128, 128, 16, "0")])
 def test_fused_vaegan_step_equals_autograd_path(S, z, B, fuse_stats, monkeypatch):
     """Same kernels, same order of arithmetic per kernel: with the BatchNorm statistics taken by the same kernel on both sides
     (VP_FUSE_BN_STATS=0) every gradient agrees to 1e-5; with the statistics from the convolution's epilogue (the default) the
