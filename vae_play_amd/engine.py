@@ -57,20 +57,20 @@ class _Plan:
         self.calls.append(["__wait_side__", None, [k], 0, 0.0, "", None])
 
     def run(self, stream_ptr: int, timers: Optional[dict] = None, start: int = 0, stop: Optional[int] = None, side=None):
-        """``side`` = (torch.cuda.Stream, list of torch.cuda.Event) or None (everything on the main stream)."""
+        """``side`` = a ``_SideCtx`` (side stream, its events, the fork event) or None (everything on the main stream)."""
         s = c_void_p(stream_ptr)
         for ci, (name, fn, a, slot, flops, tag, sev) in enumerate(self.calls[start:stop], start):
             if fn is None:                                   # main stream waits for a side event
                 if side is not None:
+                    side.flush_if_pending(a[0])              # (an event that was never recorded would not be waited for)
                     torch.cuda.current_stream().wait_event(side[1][a[0]])
                 continue
             on_side = side is not None and sev is not None
             if on_side:
-                side[2].record()                             # fork: the side stream starts after the main stream's work so far
-                side[0].wait_event(side[2])
                 a[slot] = c_void_p(side[0].cuda_stream)
-            else:
-                a[slot] = s
+                side.defer(name, fn, a, sev)                 # launched by the next flush (one fork for several launches)
+                continue
+            a[slot] = s
             timed = timers is not None and name in timers["names"]
             if timed:
                 pool = timers.get("pool")
@@ -81,13 +81,56 @@ class _Plan:
                     e0, e1 = pool[key]
                 else:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(side[0]) if on_side else e0.record()
+                e0.record()
             rc = fn(*a)
             if timed:
-                e1.record(side[0]) if on_side else e1.record()
+                e1.record()
                 timers["events"].append((name, tag, flops, e0, e1))
-            if on_side:
-                side[1][sev].record(side[0])
+            if rc != 0:
+                _lib.check(rc, name)
+
+
+class _SideCtx:
+    """Side stream of a fused plan: ``ctx[0]`` = the stream, ``ctx[1]`` = one event per side launch, ``ctx[2]`` = the fork event.
+
+    A fork (event record on the main stream + wait on the side stream) costs the MAIN stream ~6 us: the kernel behind the
+    record starts that much later (rocprofv3 timeline of the concurrent step: fifteen such gaps, ~90 us per step).  Side launches
+    can therefore be DEFERRED and handed over in batches of ``batch`` (VP_SIDE_BATCH) behind one fork -- measured SLOWER
+    (3.756 ms at 1, 3.850 at 2, 3.825 at 3, 3.811 at 4, each with enough gradient planes in the rotation; profiles/r02_notes.md
+    section 7): a weight gradient that starts one layer late no longer runs underneath the next layer's HBM-bound BatchNorm
+    backward but underneath its MFMA-bound input gradient.  The default is 1 = fork per launch.  ``flush()`` forks and launches
+    everything pending; it must run before the main stream joins or waits for the side stream, and ``flush_if_pending(k)``
+    before a wait for side event k (the plans' buffer rotation: main must not rewrite a gradient plane that a deferred weight
+    gradient has yet to read)."""
+
+    def __init__(self, n_events: int):
+        self.stream = torch.cuda.Stream()
+        self.events = [torch.cuda.Event() for _ in range(n_events)]
+        self.fork = torch.cuda.Event()
+        self.batch = max(1, int(os.environ.get("VP_SIDE_BATCH", "1")))
+        self.pending: List[tuple] = []
+
+    def __getitem__(self, i):
+        return (self.stream, self.events, self.fork)[i]
+
+    def defer(self, name, fn, args, sev):
+        self.pending.append((name, fn, list(args), sev))     # (argument list copied: input slots are re-bound per step)
+        if len(self.pending) >= self.batch:
+            self.flush()
+
+    def flush_if_pending(self, sev):
+        if any(p[3] == sev for p in self.pending):
+            self.flush()
+
+    def flush(self):
+        if not self.pending:
+            return
+        self.fork.record()                                   # the side stream starts after the main stream's work so far
+        self.stream.wait_event(self.fork)
+        pend, self.pending = self.pending, []
+        for name, fn, a, sev in pend:
+            rc = fn(*a)
+            self.events[sev].record(self.stream)
             if rc != 0:
                 _lib.check(rc, name)
 
@@ -687,6 +730,7 @@ class FusedVAEStep:
         self._bwd_dec.run(s, timers, side=side)
         if on_decoder_grads is not None:
             if side is not None:                         # the decoder's weight gradients are produced on the side stream
+                side.flush()
                 torch.cuda.current_stream().wait_stream(side[0])
             on_decoder_grads()
         self._bwd_a.run(s, timers)
@@ -706,6 +750,7 @@ class FusedVAEStep:
         else:
             self._bwd_b.run(s, timers, self._bwd_b_dense_done, side=side)
         if side is not None:
+            side.flush()
             torch.cuda.current_stream().wait_stream(side[0])
 
     def _side_ctx(self):
@@ -713,7 +758,7 @@ class FusedVAEStep:
         if not self._n_side_events or os.environ.get("VP_SIDE_WGRAD", "1") == "0":
             return None
         if not hasattr(self, "_side"):
-            self._side = (torch.cuda.Stream(), [torch.cuda.Event() for _ in range(self._n_side_events)], torch.cuda.Event())
+            self._side = _SideCtx(self._n_side_events)
         return self._side
 
     def forward_backward(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, on_decoder_grads=None,
@@ -829,6 +874,7 @@ class FusedVAEStep:
                 if tail_lo >= dense:
                     return
                 if side is not None:
+                    side.flush()
                     side[0].wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side[0]):
                         works.append(parallel.allreduce_flat_grads(g[tail_lo:dense], self.group, async_op=True))

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops, parallel
-from .engine import _Plan, _ptr
+from .engine import _Plan, _SideCtx, _ptr
 from .networks import VaeGan
 
 _ACT_RELU, _ACT_NONE, _ACT_SIGMOID = ops.ACT_RELU, ops.ACT_NONE, ops.ACT_SIGMOID
@@ -588,7 +588,7 @@ class FusedVAEGANStep:
         if not self._n_side_events:
             return None
         if not hasattr(self, "_side"):
-            self._side = (torch.cuda.Stream(), [torch.cuda.Event() for _ in range(self._n_side_events)], torch.cuda.Event())
+            self._side = _SideCtx(self._n_side_events)
         return self._side
 
     @torch.no_grad()
@@ -616,6 +616,7 @@ class FusedVAEGANStep:
         torch._foreach_add_(self._running, self._snap, alpha=-(1.0 - m))
         self._bwd.run(s, timers, side=side)
         if side is not None:
+            side.flush()
             torch.cuda.current_stream().wait_stream(side[0])
         a = self._dec_arena
         _lib.call("vp_add_f32", _ptr(a.flat_grad), _ptr(self._dec_shadow), _ptr(a.flat_grad), a.flat_grad.numel(), c_void_p(s))
