@@ -14,11 +14,11 @@ using namespace vp;
 
 // VP_HALO=0 sends the narrow-channel layers back to the implicit-GEMM kernels (A/B runs)
 // XCD-aware tile order (igemm16.h): valid when the row-tile count is a multiple of 8 and there are >= 2 column tiles
-static int xcd_map_for(long M, long N, int gz) {
+static int xcd_map_for(long M, long N, int gz, int ctile = 0) {
   const char* e = getenv("VP_XCD_MAP");
   const int mode = e ? atoi(e) : 1;
   if (mode == 0) return 0;
-  const Tile16 t = choose_tile16(M, N, gz);
+  const Tile16 t = choose_tile16(M, N, gz, false, ctile);
   const long gx = (M + t.bm - 1) / t.bm, gy = (N + t.bn - 1) / t.bn;
   if (mode == 2 || mode == 3) return (gx % 8 == 0 && gx >= 16) ? mode : 0;      // band orders (igemm16.h): any column-tile / z count
   return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
@@ -42,7 +42,7 @@ static long conv_split_tiles() {
 // VP_IGEMM16P_CFG=<n> forces configuration n of igemm16p.h wherever it applies (experiments).
 struct Launch16 { int pcfg, bm, bn; };
 static Launch16 plan16(long M, long N, int gz, int ctile, int nsplit, size_t plane_elems_a, size_t plane_elems_b, long kmin) {
-  const Tile16 t = choose_tile16(M, N, gz);
+  const Tile16 t = choose_tile16(M, N, gz, false, ctile);
   Launch16 l = {PCFG_NONE, t.bm, t.bn};
   static const int mode = [] { const char* e = getenv("VP_IGEMM16P"); return e ? atoi(e) : 1; }();
   static const int forced = [] { const char* e = getenv("VP_IGEMM16P_CFG"); return e ? atoi(e) : 0; }();
@@ -111,7 +111,7 @@ static int gather16_t(const void* big_split, const void* w_p0_split, const float
       return check_launch("vp_conv_gather_bf16x3(pipelined)");
     }
   }
-  p.xcd_map = xcd_map_for(p.M, p.N, p.nsplit);
+  p.xcd_map = xcd_map_for(p.M, p.N, p.nsplit, Cbig);
   launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig);
   return check_launch("vp_conv_gather_bf16x3");
 }
@@ -144,7 +144,7 @@ static int scatter16_t(const void* small_split, const void* w_p1_split, float* b
       return check_launch("vp_conv_scatter_bf16x3(pipelined)");
     }
   }
-  p.xcd_map = xcd_map_for(p.M, p.N, stride * stride * p.nsplit);
+  p.xcd_map = xcd_map_for(p.M, p.N, stride * stride * p.nsplit, Csmall);
   launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
   return check_launch("vp_conv_scatter_bf16x3");
 }
@@ -233,7 +233,7 @@ static StatPlan stat_plan(int family, int B, int Hs, int Ws, int Cbig, int Csmal
   const size_t act_plane = family == 0 ? (size_t)sp.M * stride * stride * Cbig : (size_t)sp.M * Csmall;
   const Launch16 l = family == 0 ? plan16(sp.M, sp.N, sp.gz, Cbig, 1, act_plane, (size_t)Csmall * Cbig * 25, 25L * Cbig)
                                  : plan16(sp.M, sp.N, sp.gz, Csmall, 1, act_plane, (size_t)Csmall * Cbig * 25, (long)stride * stride * Csmall);
-  sp.bm = (!x2 && l.pcfg != PCFG_NONE && !(family == 1 && stride != 2)) ? l.bm : choose_tile16(sp.M, sp.N, sp.gz).bm;
+  sp.bm = (!x2 && l.pcfg != PCFG_NONE && !(family == 1 && stride != 2)) ? l.bm : choose_tile16(sp.M, sp.N, sp.gz, false, family == 0 ? Cbig : Csmall).bm;
   sp.tiles_m = (int)((sp.M + sp.bm - 1) / sp.bm);
   sp.ok = 1;
   return sp;

@@ -821,7 +821,7 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 
 struct Tile16 { int bm, bn; };   // wave grid: 2 x 2, or 4 x 1 for the 32-column tiles
 
-inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false) {
+inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false, int ctile = 0) {
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
   long MINB = 384;
   if (const char* e = getenv("VP_TILE_BLOCKS")) MINB = atol(e);          // A/B knob
@@ -835,8 +835,14 @@ inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false
     }
   }
   if (getenv("VP_TILE_LOG")) fprintf(stderr, "tile16 %ldx%ldx%d\n", M, N, gz);
-  // a 32-column operand (the 32-channel end of the last decoder block): 64-column tiles would idle half the MFMAs
-  if (N <= 32 && M >= 128) return (M >= 256 && blocks(256, 32) >= MINB) ? Tile16{256, 32} : Tile16{128, 32};
+  // a 32-column operand (the 32-channel end of the last decoder block): 64-column tiles would idle half the MFMAs.
+  // Unless k runs over 64-channel chunks (ctile = the gathered / scattered side's channel count) and the launch is large: the
+  // 32-column tiles exist with 32-deep K-tiles only, and the 64x64 tile on 64-deep FAST K-tiles is 1.4-2.3x faster there even
+  // with half of its MFMA columns idle (tools/microbench_narrow_n.py: gather 5x5 s2 64 -> 32 channels 238 -> 106 us, the VAE-GAN
+  // discriminator's 64 -> 32 input gradient 252 -> 175 us; 32- and 40-channel chunks keep the narrow tiles: 134 vs 173 us).
+  static const bool deep_on = !(getenv("VP_NARROW_DEEP") && atoi(getenv("VP_NARROW_DEEP")) == 0);      // A/B knob
+  const bool deep = deep_on && ctile > 0 && ctile % 64 == 0 && (gz == 1 || M * gz >= (1L << 19));
+  if (N <= 32 && M >= 128 && !deep) return (M >= 256 && blocks(256, 32) >= MINB) ? Tile16{256, 32} : Tile16{128, 32};
   if (M >= 128 && N >= 128 && blocks(128, 128) >= MINB) return {128, 128};
   if (M >= 128 && N >= 64 && blocks(128, 64) >= MINB) return {128, 64};
   return {64, 64};
@@ -987,8 +993,8 @@ __global__ void __launch_bounds__(256) igemm16_dma_kernel(const P p) {
 }
 
 template <class P>
-inline void launch_igemm16_dma(const P& p, long M, long N, int gz, hipStream_t stream) {
-  Tile16 t = choose_tile16(M, N, gz);
+inline void launch_igemm16_dma(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0) {
+  Tile16 t = choose_tile16(M, N, gz, false, ctile);
   dim3 block(256);
   auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
   if (t.bm == 128 && t.bn == 128) {
@@ -1021,8 +1027,8 @@ inline int igemm16_bk(bool km, bool x2 = false) {
 }
 
 template <class P, int BKT, bool FAST>
-inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t stream) {
-  Tile16 t = choose_tile16(M, N, gz, P::A_KM);
+inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0) {
+  Tile16 t = choose_tile16(M, N, gz, P::A_KM, ctile);
   dim3 block(256);
   auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
   if (t.bm == 128 && t.bn == 128) {
@@ -1062,13 +1068,13 @@ inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t strea
       launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
     }
   } else {
-    const Tile16 t0 = choose_tile16(M, N, gz);
+    const Tile16 t0 = choose_tile16(M, N, gz, false, ctile);
     const bool narrow = t0.bn == 32;   // tiles that exist with 32-deep K-tiles only
-    if (ctile > 0 && ctile % 32 == 0 && igemm16_use_dma() && !narrow) launch_igemm16_dma<P>(p, M, N, gz, stream);
-    else if (ctile > 0 && ctile % 64 == 0 && bk == 64 && !narrow) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream);
-    else if (ctile > 0 && ctile % 32 == 0) launch_igemm16_bk<P, 32, true>(p, M, N, gz, stream);   // 32-channel chunks
-    else if (bk == 32 || narrow) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream);
-    else launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream);
+    if (ctile > 0 && ctile % 32 == 0 && igemm16_use_dma() && !narrow) launch_igemm16_dma<P>(p, M, N, gz, stream, ctile);
+    else if (ctile > 0 && ctile % 64 == 0 && bk == 64 && !narrow) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream, ctile);
+    else if (ctile > 0 && ctile % 32 == 0) launch_igemm16_bk<P, 32, true>(p, M, N, gz, stream, ctile);   // 32-channel chunks
+    else if (bk == 32 || narrow) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream, ctile);
+    else launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream, ctile);
   }
 }
 #endif  // __HIPCC__
