@@ -46,6 +46,9 @@ def get_conv_precision() -> str:
     return _PRECISION
 
 
+_BWD_SPLIT = os.environ.get("VP_BWD_SPLIT", "1") != "0"      # A/B knob: BatchNorm backward emits the split planes of dx
+
+
 def _split_of(x: torch.Tensor) -> torch.Tensor:
     """bf16 hi/lo planes of an NHWC activation: the copy its producer emitted in the same pass (a BatchNorm+activation
     output in bf16x3 mode carries one, valid while the tensor has not been written since), else a split pass."""
@@ -181,7 +184,7 @@ class _Conv5(Function):
             KC, B, H, W = ctx.cols
             Cs, Cb = weight.shape[0], weight.shape[1]
             if ctx.needs_input_grad[1]:
-                dys = ops.split_f32(dy)
+                dys = _split_of(dy)
                 dwc = ops.conv_wgrad_bf16x3(x, (B, KC, H // 2, W // 2), dys, tuple(dy.shape), 1, 1)      # [Cs][KC] in column order
                 dw = _grad_out(weight)
                 dw = dw if dw is not None else torch.empty_like(weight, memory_format=torch.contiguous_format)
@@ -192,7 +195,7 @@ class _Conv5(Function):
                 dx = ops.conv5_scatter_bf16x3(ops.split_f32(dy), dy.shape, p1, 8, ctx.stride)[:, :Cb]
             return dx, dw, None, None, None
         if ctx.x16:
-            dys = ops.split_f32(dy)
+            dys = _split_of(dy)
             if ctx.needs_input_grad[0]:
                 p1 = _packed(ops.pack_w5_split, weight, True)
                 dx = ops.conv5_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.stride)
@@ -280,7 +283,7 @@ class _ConvT5(Function):
         dy = _cl(dy)
         dx = dw = None
         if ctx.x16:
-            dys = ops.split_f32(dy)
+            dys = _split_of(dy)
             if ctx.needs_input_grad[0]:
                 p0 = _packed(ops.pack_w5_split, weight, False)
                 dx = ops.conv5_gather_bf16x3(dys, dy.shape, p0, weight.shape[0], None, ctx.stride, ACT_NONE)
@@ -325,8 +328,15 @@ class _BatchNormAct(Function):
         need_affine = gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         og = _grad_out(gamma) if (need_affine and ctx.needs_input_grad[1]) else None
         ob = _grad_out(beta) if (need_affine and ctx.needs_input_grad[2]) else None
-        dx, dgamma, dbeta = ops.bn_act_bwd(x, dy, mean, rstd, gamma, beta, ctx.act, ctx.slope, ctx.training, need_affine,
-                                           out_dgamma=og, out_dbeta=ob)
+        if _PRECISION == "bf16x3" and _BWD_SPLIT and x.dim() == 4 and x.shape[1] % 8 == 0 and ctx.needs_input_grad[0]:
+            # dx is almost always the output gradient of a convolution on the split-bf16 kernels: emit its operand planes from
+            # this pass (the tensor object travels through the autograd engine with its attribute; _split_of checks the version)
+            dx, dgamma, dbeta, dxs = ops.bn_act_bwd(x, dy, mean, rstd, gamma, beta, ctx.act, ctx.slope, ctx.training, need_affine,
+                                                    out_dgamma=og, out_dbeta=ob, want_split=True)
+            dx._vp_split = (dxs, dx._version)
+        else:
+            dx, dgamma, dbeta = ops.bn_act_bwd(x, dy, mean, rstd, gamma, beta, ctx.act, ctx.slope, ctx.training, need_affine,
+                                               out_dgamma=og, out_dbeta=ob)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -432,7 +442,7 @@ class _ConvK(Function):
         if ctx.pad is not None:
             Co, Ci, Cop, Cip = ctx.pad
             B, _, Ho, Wo = dy.shape
-            dys = ops.split_pad(dy, Cop) if Cop != Co else ops.split_f32(dy)
+            dys = ops.split_pad(dy, Cop) if Cop != Co else _split_of(dy)
             if ctx.needs_input_grad[0]:
                 wp = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, Cip - Ci, 0, Cop - Co)) if (Cop != Co or Cip != Ci) else weight
                 _, p1 = ops.pack_w_split(wp, False, True)
@@ -445,7 +455,7 @@ class _ConvK(Function):
                 db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Co))
             return dx, dw, db, None
         if ctx.x16:
-            dys = ops.split_f32(dy)
+            dys = _split_of(dy)
             if ctx.needs_input_grad[0]:
                 p1 = _packed(ops.pack_w_split, weight, True)
                 dx = ops.conv_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.ks, ctx.stride, ctx.xshape[2], ctx.xshape[3])

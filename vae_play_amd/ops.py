@@ -226,13 +226,19 @@ def bn_act_fwd(x, mean, rstd, gamma, beta, act: int, slope: float = 0.0, want_sp
 
 
 def bn_act_bwd(x, dy, mean, rstd, gamma, beta, act: int, slope: float, batch_stats: bool, need_affine_grads: bool = True,
-               out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None):
+               out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None, want_split: bool = False):
+    """``want_split``: also emit the bf16 hi/lo planes of dx from the same pass (C % 4 == 0); returns (dx, dgamma, dbeta, dx_split)."""
     R, C = _rc(x)
     assert _same_layout(dy, x)
     dx = torch.empty_like(x)
     dgamma = _out(out_dgamma, (C,), x.device) if need_affine_grads else None
     dbeta = _out(out_dbeta, (C,), x.device) if need_affine_grads else None
     ws = _ws(_lib.load().vp_bn_workspace_bytes(R, C), x)
+    if want_split:
+        dxs = empty_split(x.numel(), x)
+        _lib.call("vp_bn_act_bwd_split_f32", _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _pv(dxs), _p(dgamma), _p(dbeta),
+                  R, C, act, float(slope), int(batch_stats), _p(ws), ws.numel() * 4, _stream())
+        return dx, dgamma, dbeta, dxs
     _lib.call("vp_bn_act_bwd_f32", _p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dx), _p(dgamma), _p(dbeta),
               R, C, act, float(slope), int(batch_stats), _p(ws), ws.numel() * 4, _stream())
     return dx, dgamma, dbeta
