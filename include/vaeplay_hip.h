@@ -248,6 +248,12 @@ int vp_instnorm_act_fwd_f32(const float* x, float* y, float* mean, float* rstd, 
                             float slope, void* ws, size_t ws_bytes, vp_stream stream);
 int vp_instnorm_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, float* dx, int B, int R, int C,
                             int act, float slope, void* ws, size_t ws_bytes, vp_stream stream);
+/* the same with the bf16 hi/lo planes of y / dx written by the apply pass (C % 4 == 0; plane = B * R * C elements): the operand
+ * of the split-bf16 convolution that consumes the normalised activation / its input gradient (models/blocks.py:22-30) */
+int vp_instnorm_act_fwd_split_f32(const float* x, float* y, void* y_split, float* mean, float* rstd, int B, int R, int C, float eps,
+                                  int act, float slope, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_instnorm_act_bwd_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, float* dx, void* dx_split, int B,
+                                  int R, int C, int act, float slope, void* ws, size_t ws_bytes, vp_stream stream);
 /* plain activation (conv + bias + act blocks of models/blocks.py:24-30 with bn=None) */
 int vp_act_fwd_f32(const float* x, float* y, size_t n, int act, float slope, vp_stream stream);
 /* dx = dy * act'(.) evaluated from the OUTPUT y (relu/lrelu/tanh/sigmoid); dx may alias dy */

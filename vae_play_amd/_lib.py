@@ -100,6 +100,8 @@ SIGNATURES = {
     "vp_instnorm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vp_instnorm_act_fwd_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P, c_size_t, P]),
     "vp_instnorm_act_bwd_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
+    "vp_instnorm_act_fwd_split_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, P, c_size_t, P]),
+    "vp_instnorm_act_bwd_split_f32": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "vp_act_fwd_f32": (c_int, [P, P, c_size_t, c_int, c_float, P]),
     "vp_act_bwd_from_y_f32": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
     "vp_upsample2x_bilinear_fwd_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

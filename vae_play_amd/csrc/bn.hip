@@ -330,7 +330,9 @@ __global__ void __launch_bounds__(256) bn_act_fwd_tiled_kernel(const float* __re
   }
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(R, r0 + rows_per_chunk);
-  const size_t n = (size_t)R * C;
+  // split planes span all images of a batched (InstanceNorm) launch: plane = gridDim.z * R * C elements, image z at z * bxs
+  const size_t n = (size_t)R * C * gridDim.z;
+  if (y_split) y_split += blockIdx.z * bxs;
   // four rows per trip: four independent 16-B loads in flight before the first use (one load per trip left the
   // small layers at 2-3 TB/s)
   int r = r0 + ty;
@@ -381,7 +383,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
   }
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(R, r0 + rows_per_chunk);
-  const size_t n = (size_t)R * C;
+  const size_t n = (size_t)R * C * gridDim.z;          // (batched launch: see bn_act_fwd_tiled_kernel)
+  if (dx_split) dx_split += blockIdx.z * bxs;
   auto emit = [&](size_t off, const vp_f32x4& xv, const vp_f32x4& dv) {
     vp_f32x4 o;
 #pragma unroll
@@ -694,9 +697,10 @@ int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, 
 // ---- nn.InstanceNorm2d(affine=False) + activation: the same kernels with blockIdx.z = image (models/blocks.py:22) --------
 size_t vp_instnorm_workspace_bytes(int B, int R, int C) { return (size_t)B * bn_ws_floats(R, C) * sizeof(float); }
 
-int vp_instnorm_act_fwd_f32(const float* x, float* y, float* mean, float* rstd, int B, int R, int C, float eps, int act,
-                            float slope, void* ws, size_t ws_bytes, vp_stream stream) {
+static int instnorm_act_fwd_impl(const float* x, float* y, void* y_split, float* mean, float* rstd, int B, int R, int C, float eps, int act,
+                                 float slope, void* ws, size_t ws_bytes, vp_stream stream) {
   VP_REQUIRE(x && y && mean && rstd && ws && B > 0 && R > 0 && C > 0, "vp_instnorm_act_fwd_f32: bad arguments");
+  VP_REQUIRE(!y_split || C % 4 == 0, "vp_instnorm_act_fwd_split_f32: C must be a multiple of 4");
   if (ws_bytes < vp_instnorm_workspace_bytes(B, R, C)) return fail(VP_ERR_WORKSPACE, "vp_instnorm_act_fwd_f32: workspace too small");
   const BnGrid g = bn_grid(R, C);
   const size_t bxs = (size_t)R * C, bps = (size_t)2 * g.chunks_r * C;
@@ -714,7 +718,7 @@ int vp_instnorm_act_fwd_f32(const float* x, float* y, float* mean, float* rstd, 
   if (C % 4 == 0) {
     const BnGrid ga = bn_apply_grid(R, C);
     hipLaunchKernelGGL(bn_act_fwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c, B), dim3(256), 0, s, x, (const float*)mean,
-                       (const float*)rstd, (const float*)nullptr, (const float*)nullptr, y, (u16_t*)nullptr, R, C, ga.rows_per_chunk,
+                       (const float*)rstd, (const float*)nullptr, (const float*)nullptr, y, (u16_t*)y_split, R, C, ga.rows_per_chunk,
                        act, slope, bxs);
   } else {
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(bxs / 4 + 1, 256), 1, B), dim3(256), 0, s, x, (const float*)mean,
@@ -723,9 +727,21 @@ int vp_instnorm_act_fwd_f32(const float* x, float* y, float* mean, float* rstd, 
   return check_launch("vp_instnorm_act_fwd_f32(apply)");
 }
 
-int vp_instnorm_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, float* dx, int B, int R, int C,
-                            int act, float slope, void* ws, size_t ws_bytes, vp_stream stream) {
+int vp_instnorm_act_fwd_f32(const float* x, float* y, float* mean, float* rstd, int B, int R, int C, float eps, int act,
+                            float slope, void* ws, size_t ws_bytes, vp_stream stream) {
+  return instnorm_act_fwd_impl(x, y, nullptr, mean, rstd, B, R, C, eps, act, slope, ws, ws_bytes, stream);
+}
+
+int vp_instnorm_act_fwd_split_f32(const float* x, float* y, void* y_split, float* mean, float* rstd, int B, int R, int C, float eps,
+                                  int act, float slope, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(y_split, "vp_instnorm_act_fwd_split_f32: null split output");
+  return instnorm_act_fwd_impl(x, y, y_split, mean, rstd, B, R, C, eps, act, slope, ws, ws_bytes, stream);
+}
+
+static int instnorm_act_bwd_impl(const float* x, const float* dy, const float* mean, const float* rstd, float* dx, void* dx_split, int B,
+                                 int R, int C, int act, float slope, void* ws, size_t ws_bytes, vp_stream stream) {
   VP_REQUIRE(x && dy && mean && rstd && dx && ws && B > 0 && R > 0 && C > 0, "vp_instnorm_act_bwd_f32: bad arguments");
+  VP_REQUIRE(!dx_split || C % 4 == 0, "vp_instnorm_act_bwd_split_f32: C must be a multiple of 4");
   if (ws_bytes < vp_instnorm_workspace_bytes(B, R, C)) return fail(VP_ERR_WORKSPACE, "vp_instnorm_act_bwd_f32: workspace too small");
   const BnGrid g = bn_grid(R, C);
   const size_t bxs = (size_t)R * C, bps = (size_t)2 * g.chunks_r * C;
@@ -745,13 +761,24 @@ int vp_instnorm_act_bwd_f32(const float* x, const float* dy, const float* mean, 
   if (C % 4 == 0) {
     const BnGrid ga = bn_apply_grid(R, C);
     hipLaunchKernelGGL(bn_act_bwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c, B), dim3(256), 0, s, x, dy, mean, rstd,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)sum_g, (const float*)sum_gx, dx, (u16_t*)nullptr, R, C,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)sum_g, (const float*)sum_gx, dx, (u16_t*)dx_split, R, C,
                        ga.rows_per_chunk, invR, act, slope, bxs);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(grid_for(bxs / 4 + 1, 256), 1, B), dim3(256), 0, s, x, dy, mean, rstd, (const float*)nullptr,
                        (const float*)nullptr, (const float*)sum_g, (const float*)sum_gx, dx, bxs, C, invR, act, slope, (u16_t*)nullptr, bxs);
   }
   return check_launch("vp_instnorm_act_bwd_f32(apply)");
+}
+
+int vp_instnorm_act_bwd_f32(const float* x, const float* dy, const float* mean, const float* rstd, float* dx, int B, int R, int C,
+                            int act, float slope, void* ws, size_t ws_bytes, vp_stream stream) {
+  return instnorm_act_bwd_impl(x, dy, mean, rstd, dx, nullptr, B, R, C, act, slope, ws, ws_bytes, stream);
+}
+
+int vp_instnorm_act_bwd_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, float* dx, void* dx_split, int B,
+                                  int R, int C, int act, float slope, void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(dx_split, "vp_instnorm_act_bwd_split_f32: null split output");
+  return instnorm_act_bwd_impl(x, dy, mean, rstd, dx, dx_split, B, R, C, act, slope, ws, ws_bytes, stream);
 }
 
 int vp_bn_act_bwd_apply_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,

@@ -497,7 +497,12 @@ class _InstanceNormAct(Function):
     @staticmethod
     def forward(ctx, x, eps: float, act: int, slope: float):
         x = _cl(x)
-        y, mean, rstd = ops.instnorm_act_fwd(x, eps, act, slope)
+        if _PRECISION == "bf16x3" and _BWD_SPLIT and x.shape[1] % 8 == 0:
+            # as _BatchNormAct: the consumer is almost always a convolution on the split-bf16 kernels
+            y, mean, rstd, ys = ops.instnorm_act_fwd(x, eps, act, slope, want_split=True)
+            y._vp_split = (ys, y._version)
+        else:
+            y, mean, rstd = ops.instnorm_act_fwd(x, eps, act, slope)
         ctx.act, ctx.slope = act, slope
         ctx.save_for_backward(x, mean, rstd)
         return y
@@ -505,6 +510,10 @@ class _InstanceNormAct(Function):
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
+        if _PRECISION == "bf16x3" and _BWD_SPLIT and x.shape[1] % 8 == 0:
+            dx, dxs = ops.instnorm_act_bwd(x, _cl(dy), mean, rstd, ctx.act, ctx.slope, want_split=True)
+            dx._vp_split = (dxs, dx._version)
+            return dx, None, None, None
         return ops.instnorm_act_bwd(x, _cl(dy), mean, rstd, ctx.act, ctx.slope), None, None, None
 
 

@@ -244,21 +244,31 @@ def bn_act_bwd(x, dy, mean, rstd, gamma, beta, act: int, slope: float, batch_sta
     return dx, dgamma, dbeta
 
 
-def instnorm_act_fwd(x, eps: float, act: int, slope: float = 0.0):
-    """x: (B, C, H, W) channels_last -> (y, mean[B][C], rstd[B][C])."""
+def instnorm_act_fwd(x, eps: float, act: int, slope: float = 0.0, want_split: bool = False):
+    """x: (B, C, H, W) channels_last -> (y, mean[B][C], rstd[B][C]) (+ the bf16 hi/lo planes of y with ``want_split``, C % 4 == 0)."""
     B, C, H, W = x.shape
     y = torch.empty_like(x)
     mean = torch.empty((B, C), dtype=torch.float32, device=x.device)
     rstd = torch.empty((B, C), dtype=torch.float32, device=x.device)
     ws = _ws(_lib.load().vp_instnorm_workspace_bytes(B, H * W, C), x)
+    if want_split:
+        ys = empty_split(x.numel(), x)
+        _lib.call("vp_instnorm_act_fwd_split_f32", _p(x), _p(y), _pv(ys), _p(mean), _p(rstd), B, H * W, C, eps, act, slope, _p(ws),
+                  ws.numel() * 4, _stream())
+        return y, mean, rstd, ys
     _lib.call("vp_instnorm_act_fwd_f32", _p(x), _p(y), _p(mean), _p(rstd), B, H * W, C, eps, act, slope, _p(ws), ws.numel() * 4, _stream())
     return y, mean, rstd
 
 
-def instnorm_act_bwd(x, dy, mean, rstd, act: int, slope: float = 0.0):
+def instnorm_act_bwd(x, dy, mean, rstd, act: int, slope: float = 0.0, want_split: bool = False):
     B, C, H, W = x.shape
     dx = torch.empty_like(x)
     ws = _ws(_lib.load().vp_instnorm_workspace_bytes(B, H * W, C), x)
+    if want_split:
+        dxs = empty_split(x.numel(), x)
+        _lib.call("vp_instnorm_act_bwd_split_f32", _p(x), _p(dy), _p(mean), _p(rstd), _p(dx), _pv(dxs), B, H * W, C, act, slope, _p(ws),
+                  ws.numel() * 4, _stream())
+        return dx, dxs
     _lib.call("vp_instnorm_act_bwd_f32", _p(x), _p(dy), _p(mean), _p(rstd), _p(dx), B, H * W, C, act, slope, _p(ws), ws.numel() * 4,
               _stream())
     return dx
