@@ -300,7 +300,7 @@ size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, in
 size_t vp_conv_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride) {
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
   int ns = wgrad_nsplit(g);
-  if (wgrad_pair_applicable(g, ks == 5 && Hb == Hs * stride && Wb == Ws * stride)) ns = wgrad_pair_nsplit(g, ns);   // tap pairs split twice as deep
+  if (wgrad_pair_applicable(g)) ns = wgrad_pair_nsplit(g, ns);   // tap pairs split twice as deep
   return wgrad_slab_floats(g, ns) * sizeof(float);
 }
 

@@ -149,14 +149,25 @@ static int scatter16_t(const void* small_split, const void* w_p1_split, float* b
   return check_launch("vp_conv_scatter_bf16x3");
 }
 
-// Tap pairs (ProbW16P, igemm16.h): a plain 5x5 layer whose big side has 32 or 64 channels contracts TWO taps per workgroup, the two
-// taps' channels side by side in a 64- / 128-column tile: a 32-channel layer no longer pads half of a 64-column tile (and leaves the
-// slow partial-tile loads), a 64-channel layer gets the 128x128 tile's operand reuse.  13 pairs instead of 25 taps per split: the
-// pixel range is split twice as deep where the workspace allows.  A/B knob VP_WGRAD_PAIR=0.
-static inline bool wgrad_pair_applicable(const ConvGeom& g, bool plain5) {
+// Tap pairs (ProbW16T<.., PAIR>, igemm16.h): a 5x5 or 3x3 layer whose big side has 32 or 64 channels contracts TWO taps per workgroup, the
+// two taps' channels side by side in a 64- / 128-column tile: a 32-channel layer no longer pads half of a 64-column tile (and leaves the
+// slow partial-tile loads), a 64-channel layer gets a 128-column tile's operand reuse.  (nt + 1) / 2 pairs instead of nt taps per split:
+// the pixel range is split twice as deep where the workspace allows.  A 64-channel SMALL side takes the 64x128 tile (wave tiles
+// 32x64) instead of 64x64 (32x32): with 128 | 256 | ... big channels directly (kind 4), with 64 big channels on tap pairs (kind 3) --
+// the font U-Net's full-resolution layers, 110 -> ~170 TFLOP/s (tools/microbench_font_layers.py).  A/B knob VP_WGRAD_PAIR=0.
+//   kind 1: pairs, 64x64 tile (Cb = 32) | 2: pairs, 128x128 (Cb = 64, Cs % 128 == 0) | 3: pairs, 64x128 (Cb = 64, Cs % 64 == 0)
+//   kind 4: single taps, 64x128 tile (Cs % 128 == 64, Cb % 128 == 0)
+static inline int wgrad_wide_kind(const ConvGeom& g) {
   static const bool on = !(getenv("VP_WGRAD_PAIR") && atoi(getenv("VP_WGRAD_PAIR")) == 0);
-  return on && plain5 && g.nt == 25 && ((g.Cb == 32 && g.Cs % 64 == 0) || (g.Cb == 64 && g.Cs % 128 == 0));
+  if (!on) return 0;
+  const bool pair_nt = g.nt == 25 || g.nt == 9;
+  if (pair_nt && g.Cb == 32 && g.Cs % 64 == 0) return 1;
+  if (pair_nt && g.Cb == 64 && g.Cs % 128 == 0) return 2;
+  if (pair_nt && g.Cb == 64 && g.Cs % 64 == 0) return 3;
+  if (g.Cs % 128 == 64 && g.Cb % 128 == 0) return 4;
+  return 0;
 }
+static inline bool wgrad_pair_applicable(const ConvGeom& g, bool /*plain5*/ = true) { const int k = wgrad_wide_kind(g); return k >= 1 && k <= 3; }
 static inline int wgrad_pair_nsplit(const ConvGeom& g, int ns) {
   const long K = (long)g.B * g.Hs * g.Ws, maxs = (K + 511) / 512;
   long n2 = 2L * ns;
@@ -165,24 +176,36 @@ static inline int wgrad_pair_nsplit(const ConvGeom& g, int ns) {
   return n2 > ns ? (int)n2 : ns;
 }
 
-template <int MODE>      // (a template so that only the bf16 translation unit instantiates its kernels)
-static int wgrad16_pair(const void* big_split, const void* small_split, float* dw_ref, const ConvGeom& g, int ns, void* ws, vp_stream stream) {
-  ProbW16P p;
-  p.alpha = 1.f;
-  p.zero = vp_zero_page();
-  p.g = g;
-  p.big = (const u16*)big_split; p.big_plane = (size_t)g.B * g.Hb * g.Wb * g.Cb;
-  p.small = (const u16*)small_split; p.small_plane = (size_t)g.B * g.Hs * g.Ws * g.Cs;
-  p.slab = (float*)ws; p.M = g.Cs; p.N = 2 * g.Cb; p.K = g.B * g.Hs * g.Ws;
-  p.nsplit = ns;
-  const int per = (p.K + ns - 1) / ns;
-  p.k_per_split = ((per + 31) / 32) * 32;
-  const unsigned gz = 13u * (unsigned)ns;
-  if (g.Cb == 32) hipLaunchKernelGGL((igemm16_kernel<ProbW16P, 64, 64, 2, 2, 32, true>), dim3(g.Cs / 64, 1, gz), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((igemm16_kernel<ProbW16P, 128, 128, 2, 2, 32, true>), dim3(g.Cs / 128, 1, gz), dim3(256), 0, (hipStream_t)stream, p);
-  int rc = check_launch("vp_conv_wgrad_bf16x3(tap pairs)");
+template <bool K5>      // (a template so that only the bf16 translation unit instantiates its kernels)
+static int wgrad16_wide(int kind, const void* big_split, const void* small_split, float* dw_ref, const ConvGeom& g, int ns, void* ws,
+                        vp_stream stream) {
+  const int per = ((long)g.B * g.Hs * g.Ws + ns - 1) / ns;
+  auto fill = [&](auto& p, int N) {
+    p.alpha = 1.f;
+    p.zero = vp_zero_page();
+    p.g = g;
+    p.big = (const u16*)big_split; p.big_plane = (size_t)g.B * g.Hb * g.Wb * g.Cb;
+    p.small = (const u16*)small_split; p.small_plane = (size_t)g.B * g.Hs * g.Ws * g.Cs;
+    p.slab = (float*)ws; p.M = g.Cs; p.N = N; p.K = g.B * g.Hs * g.Ws;
+    p.nsplit = ns;
+    p.k_per_split = ((per + 31) / 32) * 32;
+  };
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 4) {
+    ProbW16T<K5, 0, false> p;
+    fill(p, g.Cb);
+    hipLaunchKernelGGL((igemm16_kernel<ProbW16T<K5, 0, false>, 64, 128, 2, 2, 32, true>), dim3(g.Cs / 64, g.Cb / 128, (unsigned)(g.nt * ns)), dim3(256), 0, s, p);
+  } else {
+    ProbW16T<K5, 0, true> p;
+    fill(p, 2 * g.Cb);
+    const unsigned gz = (unsigned)((g.nt + 1) / 2) * (unsigned)ns;
+    if (kind == 1) hipLaunchKernelGGL((igemm16_kernel<ProbW16T<K5, 0, true>, 64, 64, 2, 2, 32, true>), dim3(g.Cs / 64, 1, gz), dim3(256), 0, s, p);
+    else if (kind == 2) hipLaunchKernelGGL((igemm16_kernel<ProbW16T<K5, 0, true>, 128, 128, 2, 2, 32, true>), dim3(g.Cs / 128, 1, gz), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((igemm16_kernel<ProbW16T<K5, 0, true>, 64, 128, 2, 2, 32, true>), dim3(g.Cs / 64, 1, gz), dim3(256), 0, s, p);
+  }
+  int rc = check_launch("vp_conv_wgrad_bf16x3(wide tiles / tap pairs)");
   if (rc) return rc;
-  return slab_reduce_launch((const float*)ws, dw_ref, g.Cs, g.Cb, ns, (hipStream_t)stream, g.nt);
+  return slab_reduce_launch((const float*)ws, dw_ref, g.Cs, g.Cb, ns, s, g.nt);
 }
 
 template <class PW>
@@ -305,11 +328,16 @@ static int wgrad16(const void* big_split, const void* small_split, float* dw_ref
     if (!plain5) return wgrad16_t<ProbW16KX>(big_split, small_split, dw_ref, g, ns, ws, stream, alpha);
     return wgrad16_t<ProbW16X>(big_split, small_split, dw_ref, g, ns, ws, stream, alpha);
   } else {
-  if (!plain5) return wgrad16_t<ProbW16K>(big_split, small_split, dw_ref, g, ns, ws, stream);
-  if (wgrad_pair_applicable(g, plain5)) {
-    const int n2 = wgrad_pair_nsplit(g, ns);        // deeper split when the caller's workspace holds it (the *_workspace_bytes query asks for it)
-    return wgrad16_pair<0>(big_split, small_split, dw_ref, g, ws_bytes >= wgrad_slab_floats(g, n2) * sizeof(float) ? n2 : ns, ws, stream);
+  if (const int kind = wgrad_wide_kind(g)) {
+    int n = ns;
+    if (kind <= 3) {      // deeper split when the caller's workspace holds it (the *_workspace_bytes query asks for it)
+      const int n2 = wgrad_pair_nsplit(g, ns);
+      n = ws_bytes >= wgrad_slab_floats(g, n2) * sizeof(float) ? n2 : ns;
+    }
+    return plain5 ? wgrad16_wide<true>(kind, big_split, small_split, dw_ref, g, n, ws, stream)
+                  : wgrad16_wide<false>(kind, big_split, small_split, dw_ref, g, n, ws, stream);
   }
+  if (!plain5) return wgrad16_t<ProbW16K>(big_split, small_split, dw_ref, g, ns, ws, stream);
   return wgrad16_t<ProbW16>(big_split, small_split, dw_ref, g, ns, ws, stream);
   }
 }
