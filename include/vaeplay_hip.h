@@ -171,6 +171,17 @@ size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, in
 int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref,
                           int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
                           void* ws, size_t ws_bytes, vp_stream stream);
+/* Weight gradient of a 3x3 / stride 1 / padding 1 nn.Conv2d with a handful of channels on both sides (Cin <= 40, Cout <= 8: the mask /
+ * edge heads of models/networks_BE.py:39-66 via models/blocks.py:9-17), exact fp32 on the vector ALUs: x (B, H, W, Cin) and dy (B, H, W,
+ * Cout) NHWC, dw_ref (Cout, Cin, 3, 3); bit-reproducible.  vp_conv3_small_wgrad_workspace_bytes() == 0: shape not taken. */
+size_t vp_conv3_small_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int vp_conv3_small_wgrad_f32(const float* x, const float* dy, float* dw_ref, int B, int H, int W, int Cin, int Cout,
+                             void* ws, size_t ws_bytes, vp_stream stream);
+/* ... and their forward pass / input gradient: y = bias + conv3x3(x, w) and dx = conv3x3^T(dy, w), one output pixel per thread, exact
+ * fp32, reading the reference weight layout (Cout, Cin, 3, 3) directly (no packing, no channel padding). */
+int vp_conv3_small_fwd_f32(const float* x, const float* w_ref, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
+                           vp_stream stream);
+int vp_conv3_small_dgrad_f32(const float* dy, const float* w_ref, float* dx, int B, int H, int W, int Cin, int Cout, vp_stream stream);
 /* Second half of every weight-gradient entry point above (the gradient of nn.Conv2d / nn.ConvTranspose2d weights,
  * models/networks.py:14,38): the K-split launch leaves slab[split][tap][Csmall][Cbig]; this sums the splits in a fixed order
  * (even splits, odd splits, their sum: bit-reproducible, no atomics) and writes the reference layout dw[Csmall][Cbig][tap].

@@ -81,6 +81,10 @@ SIGNATURES = {
     "vp_conv5_wgrad_bf16x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vp_conv5_wgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "vp_wgrad_slab_reduce_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_conv3_small_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
+    "vp_conv3_small_wgrad_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "vp_conv3_small_fwd_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_conv3_small_dgrad_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_bn_small_fwd_f32": (c_int, [P, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P, c_int, c_float, P]),
     "vp_bn_small_bwd_f32": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_int, P]),
     "vp_bn_act_fwd_split_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, P]),

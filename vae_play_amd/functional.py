@@ -46,6 +46,8 @@ def get_conv_precision() -> str:
     return _PRECISION
 
 
+_SMALL3 = os.environ.get("VP_SMALL3", "1") != "0"           # A/B knob: VALU kernels for the few-channel 3x3 convolutions ("w": weight gradient only)
+_SMALL3_ALL = os.environ.get("VP_SMALL3", "1") not in ("0", "w")
 _BWD_SPLIT = os.environ.get("VP_BWD_SPLIT", "1") != "0"      # A/B knob: BatchNorm backward emits the split planes of dx
 
 
@@ -405,6 +407,18 @@ class _ConvK(Function):
         ctx.xshape = tuple(x.shape)
         ctx.pad = None
         Co, Ci = weight.shape[0], weight.shape[1]
+        # a handful of channels on both sides (the networks_BE heads): the weight gradient is a reduction over the pixels into a few
+        # hundred numbers -- exact-fp32 VALU kernel (csrc/small3.hip) instead of a 64 x 64 MFMA tile that is 92 - 98 % padding
+        ctx.small3 = (_SMALL3 and ks == 3 and stride == 1 and x.dtype == torch.float32
+                      and ops.conv3_small_wgrad_applicable(x.shape[0], x.shape[2], x.shape[3], Ci, Co))
+        x32 = x if ctx.small3 else None
+        ctx.direct3 = ctx.small3 and _SMALL3_ALL
+        if ctx.direct3:                 # forward and input gradient too: one output pixel per thread, no packing / padding / split
+            y = ops.conv3_small_fwd(x, weight.contiguous(), bias)
+            ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
+            ctx.bias_param = bias
+            ctx.save_for_backward(x, weight, x32)
+            return y
         if _PRECISION == "bf16x3" and not ctx.x16:
             # a channel count that is not a multiple of 8 on either side (32 + 2 coordinate channels in, 1 or 2 channels out):
             # zero-pad it to the next multiple of 8 and stay on the split-bf16 kernels -- the exact-f32 tile kernels run these
@@ -419,7 +433,7 @@ class _ConvK(Function):
             ctx.pad = (Co, Ci, Cop, Cip)
             ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
             ctx.bias_param = bias
-            ctx.save_for_backward(xs, weight)
+            ctx.save_for_backward(xs, weight, x32)
             return y[:, :Co] if Cop != Co else y
         if ctx.x16:                     # split-bf16 kernels (set_conv_precision("bf16x3"), channel counts multiples of 8)
             xs = _split_of(x)
@@ -431,14 +445,24 @@ class _ConvK(Function):
             y = ops.conv_gather(x, p0, bias, ks, stride, ACT_NONE)
         ctx.stride, ctx.ks, ctx.has_bias = stride, ks, bias is not None
         ctx.bias_param = bias
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, x32)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, x32 = ctx.saved_tensors
         dy = _cl(dy)
         dx = dw = db = None
+        small_dw = None
+        if ctx.small3 and ctx.needs_input_grad[1]:
+            small_dw = ops.conv3_small_wgrad(x32, dy, out=_grad_out(weight))
+        if ctx.direct3:
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv3_small_dgrad(dy, weight.contiguous())
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                B, C, H, W = dy.shape
+                db = ops.colsum(dy.permute(0, 2, 3, 1).reshape(B * H * W, C), out=_grad_out(ctx.bias_param))
+            return dx, small_dw, db, None
         if ctx.pad is not None:
             Co, Ci, Cop, Cip = ctx.pad
             B, _, Ho, Wo = dy.shape
@@ -448,7 +472,9 @@ class _ConvK(Function):
                 _, p1 = ops.pack_w_split(wp, False, True)
                 dx = ops.conv_scatter_bf16x3(dys, (B, Cop, Ho, Wo), p1, Cip, ctx.ks, ctx.stride, ctx.xshape[2], ctx.xshape[3])
                 dx = dx[:, :Ci] if Cip != Ci else dx
-            if ctx.needs_input_grad[1]:
+            if small_dw is not None:
+                dw = small_dw
+            elif ctx.needs_input_grad[1]:
                 dw = ops.conv_wgrad_bf16x3(x, (B, Cip, ctx.xshape[2], ctx.xshape[3]), dys, (B, Cop, Ho, Wo), ctx.ks, ctx.stride)
                 dw = dw[:Co, :Ci].contiguous() if (Cop != Co or Cip != Ci) else dw
             if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -459,13 +485,17 @@ class _ConvK(Function):
             if ctx.needs_input_grad[0]:
                 p1 = _packed(ops.pack_w_split, weight, True)
                 dx = ops.conv_scatter_bf16x3(dys, dy.shape, p1, weight.shape[1], ctx.ks, ctx.stride, ctx.xshape[2], ctx.xshape[3])
-            if ctx.needs_input_grad[1]:
+            if small_dw is not None:
+                dw = small_dw
+            elif ctx.needs_input_grad[1]:
                 dw = ops.conv_wgrad_bf16x3(x, ctx.xshape, dys, tuple(dy.shape), ctx.ks, ctx.stride, out=_grad_out(weight))
         else:
             if ctx.needs_input_grad[0]:
                 p1 = _packed(ops.pack_w, weight, True)
                 dx = ops.conv_scatter(dy, p1, ctx.ks, ctx.stride, x.shape[2], x.shape[3])
-            if ctx.needs_input_grad[1]:
+            if small_dw is not None:
+                dw = small_dw
+            elif ctx.needs_input_grad[1]:
                 dw = ops.conv_wgrad(x, dy, ctx.ks, ctx.stride, out=_grad_out(weight))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             B, C, H, W = dy.shape

@@ -173,6 +173,43 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] 
     return gemm(dy, 1, N, x, 1, K, N, K, M, 2, out=out)
 
 
+def conv3_small_wgrad_applicable(B: int, H: int, W: int, Cin: int, Cout: int) -> bool:
+    return _lib.load().vp_conv3_small_wgrad_workspace_bytes(B, H, W, Cin, Cout) > 0
+
+
+def conv3_small_wgrad(x: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW (Cout, Cin, 3, 3) of a 3x3 / stride 1 / padding 1 convolution with few channels; x, dy: (B, C, H, W) channels_last fp32."""
+    B, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    assert _is_nhwc(x) and _is_nhwc(dy) and tuple(dy.shape) == (B, Co, H, W)
+    nbytes = _lib.load().vp_conv3_small_wgrad_workspace_bytes(B, H, W, Ci, Co)
+    if nbytes == 0:
+        raise _lib.VaePlayHipError("vp_conv3_small_wgrad_f32 does not take this shape")
+    ws = _ws(nbytes, x)
+    dw = _out(out, (Co, Ci, 3, 3), x.device)
+    _lib.call("vp_conv3_small_wgrad_f32", _p(x), _p(dy), _p(dw), B, H, W, Ci, Co, _p(ws), ws.numel() * 4, _stream())
+    return dw
+
+
+def conv3_small_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """y = bias + conv3x3(x) (stride 1, padding 1) for few channels; x (B, Ci, H, W) channels_last, weight (Co, Ci, 3, 3)."""
+    B, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    assert _is_nhwc(x) and weight.is_contiguous()
+    y = empty_cl(B, Co, H, W, x)
+    _lib.call("vp_conv3_small_fwd_f32", _p(x), _p(weight), _p(bias), _p(y), B, H, W, Ci, Co, _stream())
+    return y
+
+
+def conv3_small_dgrad(dy: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    B, Co, H, W = dy.shape
+    Ci = weight.shape[1]
+    assert _is_nhwc(dy) and weight.is_contiguous()
+    dx = empty_cl(B, Ci, H, W, dy)
+    _lib.call("vp_conv3_small_dgrad_f32", _p(dy), _p(weight), _p(dx), B, H, W, Ci, Co, _stream())
+    return dx
+
+
 def wgrad_slab_reduce(slab: torch.Tensor, Cs: int, Cb: int, nt: int, variant: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """slab[nsplit][nt][Cs][Cb] (the K-split weight-gradient launches' workspace) -> dw[Cs][Cb][nt], splits summed in a fixed order."""
     nsplit = slab.numel() // (nt * Cs * Cb)
