@@ -22,6 +22,33 @@ namespace vp {
 constexpr int S3_TH = 8, S3_TW = 32, S3_P = S3_TH * S3_TW;
 constexpr int S3_MAX_CI = 36, S3_MAX_CO = 8;      // (36 input channels: the forward tile + weights fill 59 KB of LDS)
 
+// halo tile (TH + 2) x (TW + 2) pixels of image b with origin (h0 - 1, w0 - 1) -> LDS [pixel][CP] (zero outside the image; the
+// padding channels [C, CP) are zeroed once by the caller); 16-B loads when C % 4 == 0
+__device__ __forceinline__ void stage_halo(float* __restrict__ xs, const float* __restrict__ x, int b, int h0, int w0, int H, int W, int C,
+                                           int CP, int tid) {
+  if ((C & 3) == 0) {
+    const int q = C >> 2, rowq = (S3_TW + 2) * q;
+    for (int idx = tid; idx < (S3_TH + 2) * rowq; idx += 256) {
+      const int r = idx / rowq, j = idx - r * rowq, c = j / q, ch = (j - c * q) * 4;
+      const int h = h0 - 1 + r, w = w0 - 1 + c;
+      vp_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (h >= 0 && h < H && w >= 0 && w < W) v = *reinterpret_cast<const vp_f32x4*>(x + ((size_t)(b * H + h) * W + w) * C + ch);
+      *reinterpret_cast<vp_f32x4*>(xs + (r * (S3_TW + 2) + c) * CP + ch) = v;
+    }
+  } else {
+    const int rowlen = (S3_TW + 2) * C;
+    for (int r = 0; r < S3_TH + 2; ++r) {
+      const int h = h0 - 1 + r;
+      const bool hok = h >= 0 && h < H;
+      const float* src = x + ((size_t)(b * H + (hok ? h : 0)) * W) * C;
+      for (int j = tid; j < rowlen; j += 256) {
+        const int c = j / C, ch = j - c * C, w = w0 - 1 + c;
+        xs[(r * (S3_TW + 2) + c) * CP + ch] = (hok && w >= 0 && w < W) ? src[(size_t)w * C + ch] : 0.f;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) conv3_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                 float* __restrict__ slab, int B, int H, int W, int Ci, int Co,
                                                                 int tiles_h, int tiles_w, int ntiles) {
@@ -45,24 +72,26 @@ __global__ void __launch_bounds__(256) conv3_small_wgrad_kernel(const float* __r
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  const int rowlen = (S3_TW + 2) * Ci;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int b = t / (tiles_h * tiles_w), rem = t - b * (tiles_h * tiles_w);
     const int th = rem / tiles_w, tw = rem - th * tiles_w;
     const int h0 = th * S3_TH, w0 = tw * S3_TW;
-    for (int r = 0; r < S3_TH + 2; ++r) {
-      const int h = h0 - 1 + r;
-      const bool hok = h >= 0 && h < H;
-      const float* src = x + ((size_t)(b * H + (hok ? h : 0)) * W) * Ci;
-      for (int j = tid; j < rowlen; j += 256) {
-        const int c = j / Ci, ch = j - c * Ci, w = w0 - 1 + c;
-        xs[(r * (S3_TW + 2) + c) * CiP + ch] = (hok && w >= 0 && w < W) ? src[(size_t)w * Ci + ch] : 0.f;
+    stage_halo(xs, x, b, h0, w0, H, W, Ci, CiP, tid);
+    if ((Co & 3) == 0) {                                             // 16-B loads when the pixel rows are 16-B aligned
+      const int q = Co >> 2;
+      for (int idx = tid; idx < S3_P * q; idx += 256) {
+        const int pix = idx / q, ch = (idx - pix * q) * 4;
+        const int r = pix / S3_TW, c = pix - r * S3_TW, h = h0 + r, w = w0 + c;
+        vp_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (h < H && w < W) v = *reinterpret_cast<const vp_f32x4*>(dy + ((size_t)(b * H + h) * W + w) * Co + ch);
+        *reinterpret_cast<vp_f32x4*>(dys + pix * CoP + ch) = v;
       }
-    }
-    for (int idx = tid; idx < S3_P * Co; idx += 256) {
-      const int pix = idx / Co, ch = idx - pix * Co;
-      const int r = pix / S3_TW, c = pix - r * S3_TW, h = h0 + r, w = w0 + c;
-      dys[pix * CoP + ch] = (h < H && w < W) ? dy[((size_t)(b * H + h) * W + w) * Co + ch] : 0.f;
+    } else {
+      for (int idx = tid; idx < S3_P * Co; idx += 256) {
+        const int pix = idx / Co, ch = idx - pix * Co;
+        const int r = pix / S3_TW, c = pix - r * S3_TW, h = h0 + r, w = w0 + c;
+        dys[pix * CoP + ch] = (h < H && w < W) ? dy[((size_t)(b * H + h) * W + w) * Co + ch] : 0.f;
+      }
     }
     __syncthreads();
     if (active) {
@@ -127,20 +156,11 @@ __global__ void __launch_bounds__(256) conv3_small_kernel(const float* __restric
   for (int n = 0; n < NP; ++n) b0[n] = (!DGRAD && bias && n < N) ? bias[n] : 0.f;
   __syncthreads();
   const int r = tid / S3_TW, c = tid - r * S3_TW;
-  const int rowlen = (S3_TW + 2) * K;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int b = t / (tiles_h * tiles_w), rem = t - b * (tiles_h * tiles_w);
     const int th = rem / tiles_w, tw = rem - th * tiles_w;
     const int h0 = th * S3_TH, w0 = tw * S3_TW;
-    for (int rr = 0; rr < S3_TH + 2; ++rr) {
-      const int h = h0 - 1 + rr;
-      const bool hok = h >= 0 && h < H;
-      const float* src = in + ((size_t)(b * H + (hok ? h : 0)) * W) * K;
-      for (int j = tid; j < rowlen; j += 256) {
-        const int cc = j / K, ch = j - cc * K, ww = w0 - 1 + cc;
-        xs[(rr * (S3_TW + 2) + cc) * KP + ch] = (hok && ww >= 0 && ww < W) ? src[(size_t)ww * K + ch] : 0.f;
-      }
-    }
+    stage_halo(xs, in, b, h0, w0, H, W, K, KP, tid);
     __syncthreads();
     float acc[NP];
 #pragma unroll
