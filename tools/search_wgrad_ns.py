@@ -5,10 +5,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-shapes = {"128x64": 16, "256x128": 8, "512x256": 2, "64x64": 16}
+# base = the heuristic's current split count per "CsxCb" key (tap-pair layers: before the pair rule doubles it)
+shapes = {"128x64": 16, "256x128": 12, "512x256": 3, "512x512": 2}
 best = {}
 for key, base in shapes.items():
-    for cand in sorted({max(1, int(round(base * f))) for f in (0.5, 0.75, 1.25, 1.5, 2.0)} - {base}):
+    for cand in sorted({max(1, int(round(base * f))) for f in (0.5, 0.67, 1.34, 1.5, 2.0)} - {base}):
         cfg = ",".join([f"{k}:{v}" for k, v in best.items()] + [f"{key}:{cand}"])
         ref = ",".join([f"{k}:{v}" for k, v in best.items()]) or "none:1"
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab_build.py"), "VP_WGRAD_NS", ref, cfg, "3", "30"],
