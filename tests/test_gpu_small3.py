@@ -35,7 +35,8 @@ def _ref_conv(x, w, b):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,bias", [(2, 16, 32, 8, 8, False), (1, 9, 33, 34, 8, False), (3, 8, 8, 10, 4, True), (2, 24, 40, 4, 1, True),
-                                              (1, 70, 130, 36, 8, False), (2, 40, 24, 4, 8, True), (2, 5, 3, 1, 1, True), (2, 17, 31, 12, 5, True)])
+                                              (1, 70, 130, 36, 8, False), (2, 40, 24, 4, 8, True), (2, 5, 3, 1, 1, True), (2, 17, 31, 12, 5, True),
+                                              (2, 33, 70, 36, 1, True), (1, 20, 40, 33, 4, False), (2, 12, 64, 30, 6, True)])
 def test_forward_and_input_gradient_against_fp64(B, H, W, Ci, Co, bias):
     from vae_play_amd import ops
     g = torch.Generator().manual_seed(B + H * 3 + Ci * 7 + Co)
@@ -54,8 +55,9 @@ def test_forward_and_input_gradient_against_fp64(B, H, W, Ci, Co, bias):
 
 def test_shapes_outside_the_kernel_are_refused():
     from vae_play_amd import _lib, ops
-    assert not ops.conv3_small_wgrad_applicable(1, 8, 8, 48, 8)
+    assert not ops.conv3_small_wgrad_applicable(1, 8, 8, 48, 8)        # Cin * Cout > 288: the MFMA kernels' territory
     assert not ops.conv3_small_wgrad_applicable(1, 8, 8, 8, 16)
+    assert not ops.conv3_small_wgrad_applicable(1, 8, 8, 64, 1)
     x = torch.zeros(1, 48, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last)
     dy = torch.zeros(1, 8, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last)
     with pytest.raises(_lib.VaePlayHipError):
