@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("VP_ENV_DYNAMIC", "1")      # (inherited by the probe and the ab_env.py children: per-launch knob reads, csrc/env.h)
 probe = subprocess.run([sys.executable, "-c", "import os,sys,torch\nsys.path.insert(0, %r)\nimport vae_play_amd as V\nfrom vae_play_amd import optim\nfrom vae_play_amd.engine import FusedVAEStep\ntorch.manual_seed(0)\nvae=V.VAE(128,128,3).cuda()\nopt=optim.Adam(vae.parameters(),lr=1e-4)\nst=FusedVAEStep(vae,opt,32,128,3)\nx,e=torch.rand(32,3,128,128,device='cuda'),torch.randn(32,128,device='cuda')\nst.step(x,e)\nos.environ['VP_TILE_LOG']='1'\nst.step(x,e)\ntorch.cuda.synchronize()" % ROOT],
                        capture_output=True, text=True, timeout=300)
 shapes = sorted({m for m in re.findall(r"tile16 (\d+x\d+x\d+)", probe.stderr)})

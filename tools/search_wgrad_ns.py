@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("VP_ENV_DYNAMIC", "1")
 # base = the heuristic's current split count per "CsxCb" key (tap-pair layers: before the pair rule doubles it)
 shapes = {"128x64": 16, "256x128": 12, "512x256": 3, "512x512": 2}
 best = {}

@@ -5,6 +5,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("VP_ENV_DYNAMIC", "1")      # the library then re-reads its per-launch knobs on every launch (csrc/env.h)
 from vae_play_amd import ops  # noqa: E402
 
 for M, N, K in ((4, 1024, 8192), (32, 1024, 32768), (4, 8192, 64), (4, 64, 1024), (12, 512, 16384), (4, 1024, 16384), (12, 512, 4096),

@@ -19,7 +19,7 @@ inline BnGrid bn_grid(int R, int C) {
   BnGrid g;
   g.chunks_c = (C + BN_CH - 1) / BN_CH;
   int total = 1024;
-  if (const char* e = getenv("VP_BN_BLOCKS")) total = atoi(e);          // A/B knob
+  if (const char* e = VP_GETENV("VP_BN_BLOCKS")) total = atoi(e);          // A/B knob
   int want = total / g.chunks_c;
   if (want < 1) want = 1;
   int maxr = (R + 63) / 64;   // at least ~64 rows per chunk
@@ -419,9 +419,9 @@ inline BnGrid bn_apply_grid(int R, int C) {
   BnGrid g;
   g.chunks_c = (C + BN_CH - 1) / BN_CH;
   int total = 4096;
-  if (const char* e = getenv("VP_BN_APPLY_BLOCKS")) total = atoi(e);    // A/B knob
+  if (const char* e = VP_GETENV("VP_BN_APPLY_BLOCKS")) total = atoi(e);    // A/B knob
   int rows_min = 4;                                                     // trips of 16 rows per workgroup, at least
-  if (const char* e = getenv("VP_BN_APPLY_TRIPS")) rows_min = atoi(e);
+  if (const char* e = VP_GETENV("VP_BN_APPLY_TRIPS")) rows_min = atoi(e);
   int want = total / g.chunks_c;
   if (want < 1) want = 1;
   int maxr = (R + BN_TY * rows_min - 1) / (BN_TY * rows_min);

@@ -2,8 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdarg>
 #include "../../include/vaeplay_hip.h"
+#include "env.h"
 
 namespace vp {
 

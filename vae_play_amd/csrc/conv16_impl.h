@@ -15,7 +15,7 @@ using namespace vp;
 // VP_HALO=0 sends the narrow-channel layers back to the implicit-GEMM kernels (A/B runs)
 // XCD-aware tile order (igemm16.h): valid when the row-tile count is a multiple of 8 and there are >= 2 column tiles
 static int xcd_map_for(long M, long N, int gz, int ctile = 0) {
-  const char* e = getenv("VP_XCD_MAP");
+  const char* e = VP_GETENV("VP_XCD_MAP");
   const int mode = e ? atoi(e) : 1;
   if (mode == 0) return 0;
   const Tile16 t = choose_tile16(M, N, gz, false, ctile);
@@ -31,7 +31,7 @@ static bool halo_enabled() {
 
 // layers with fewer output tiles than this split K in two (A/B knob VP_CONV_SPLIT_TILES)
 static long conv_split_tiles() {
-  const char* e = getenv("VP_CONV_SPLIT_TILES");
+  const char* e = VP_GETENV("VP_CONV_SPLIT_TILES");
   return e ? atol(e) : 384;
 }
 
@@ -62,7 +62,7 @@ static Launch16 plan16(long M, long N, int gz, int ctile, int nsplit, size_t pla
   return l;
 }
 static int xcd_map_tile(long M, long N, int bm, int bn) {
-  const char* e = getenv("VP_XCD_MAP");
+  const char* e = VP_GETENV("VP_XCD_MAP");
   if (e && atoi(e) == 0) return 0;
   const long gx = (M + bm - 1) / bm, gy = (N + bn - 1) / bn;
   return (gx % 8 == 0 && gy >= 2) ? 1 : 0;

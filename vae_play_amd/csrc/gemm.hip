@@ -321,11 +321,11 @@ __global__ void __launch_bounds__(256) skinny_kn_kernel(const float* __restrict_
 // Split count of the skinny kernels (0: shape not eligible).  mode 0 / 1 as in vp_gemm_f32.
 inline int skinny_nsplit(int mode, long M, long N, long K) {
   if (mode > 1 || M > 64 || N < 128 || K % SK_KT) return 0;
-  if (const char* e = getenv("VP_GEMM_SKINNY")) if (atoi(e) == 0) return 0;   // A/B knob
+  if (const char* e = VP_GETENV("VP_GEMM_SKINNY")) if (atoi(e) == 0) return 0;   // A/B knob
   const long colblocks = (N + 127) / 128;
   const long unit = mode == 0 ? 256 : 4 * SK_KT;      // smallest K range worth a workgroup
   long blocks = 512;
-  if (const char* e = getenv("VP_SKINNY_BLOCKS")) blocks = atol(e);            // A/B knob
+  if (const char* e = VP_GETENV("VP_SKINNY_BLOCKS")) blocks = atol(e);            // A/B knob
   long want = (blocks + colblocks - 1) / colblocks;
   long maxs = K / unit;
   if (maxs < 1) maxs = 1;

@@ -824,8 +824,8 @@ struct Tile16 { int bm, bn; };   // wave grid: 2 x 2, or 4 x 1 for the 32-column
 inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false, int ctile = 0) {
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
   long MINB = 384;
-  if (const char* e = getenv("VP_TILE_BLOCKS")) MINB = atol(e);          // A/B knob
-  if (const char* e = getenv("VP_TILE_OVERRIDE")) {                      // A/B knob: "MxNxgz:BMxBN,..." per launch shape
+  if (const char* e = VP_GETENV("VP_TILE_BLOCKS")) MINB = atol(e);          // A/B knob
+  if (const char* e = VP_GETENV("VP_TILE_OVERRIDE")) {                      // A/B knob: "MxNxgz:BMxBN,..." per launch shape
     char key[64];
     snprintf(key, sizeof(key), "%ldx%ldx%d:", M, N, gz);
     if (const char* q = strstr(e, key)) {
@@ -834,7 +834,7 @@ inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false
         return {bm, bn};
     }
   }
-  if (getenv("VP_TILE_LOG")) fprintf(stderr, "tile16 %ldx%ldx%d\n", M, N, gz);
+  if (VP_GETENV("VP_TILE_LOG")) fprintf(stderr, "tile16 %ldx%ldx%d\n", M, N, gz);
   // a 32-column operand (the 32-channel end of the last decoder block): 64-column tiles would idle half the MFMAs.
   // Unless k runs over 64-channel chunks (ctile = the gathered / scattered side's channel count) and the launch is large: the
   // 32-column tiles exist with 32-deep K-tiles only, and the 64x64 tile on 64-deep FAST K-tiles is 1.4-2.3x faster there even
@@ -1010,7 +1010,7 @@ inline void launch_igemm16_dma(const P& p, long M, long N, int gz, hipStream_t s
 // register-staged BK=64 kernel on every layer (profiles/r01_c_notes.md): a 32-deep tile is 768 MFMA cycles,
 // too short to cover the DMA latency; it needs counted vmcnt + raw barriers + a third buffer to pay off.
 inline int igemm16_use_dma() {
-  const char* e = getenv("VP_IGEMM16_DMA");       // read per call: tools/ab_env.py flips it inside one process
+  const char* e = VP_GETENV("VP_IGEMM16_DMA");
   return e ? atoi(e) : 0;
 }
 
@@ -1018,7 +1018,7 @@ inline int igemm16_use_dma() {
 // gradient (its [pixel][channel] LDS images at depth 64 leave one workgroup per CU).  Measured on
 // MI355X, profiles/; VP_IGEMM16_BK=32|64 overrides both for A/B runs.
 inline int igemm16_bk(bool km, bool x2 = false) {
-  const char* e = getenv(km ? "VP_IGEMM16_BK_W" : "VP_IGEMM16_BK");
+  const char* e = km ? VP_GETENV("VP_IGEMM16_BK_W") : VP_GETENV("VP_IGEMM16_BK");
   const int forced = e ? atoi(e) : 0;
   if (forced == 32 || forced == 64) return forced;
   // the two-product fp16 mode stages three planes instead of four: the weight gradient's 64-deep K-tile then leaves two

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include "env.h"
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define VP_HD __host__ __device__ __forceinline__
@@ -466,8 +467,8 @@ inline int wgrad_nsplit(const ConvGeom& g) {
   // per-shape search on the final schedule (tools/search_wgrad_ns.py): the single-tile layers (25 workgroups per split) keep
   // 16 splits, the 2- and 8-tile layers gain 0.6 % / 0.35 % of the step with 12 and 3 splits instead of 8 and 2
   if (tiles >= 50) target = 600;
-  if (const char* e = getenv("VP_WGRAD_BLOCKS")) target = atol(e);      // A/B knob
-  if (const char* e = getenv("VP_WGRAD_NS")) {                          // A/B knob: "CsxCb:ns,CsxCb:ns" overrides per shape
+  if (const char* e = VP_GETENV("VP_WGRAD_BLOCKS")) target = atol(e);      // A/B knob
+  if (const char* e = VP_GETENV("VP_WGRAD_NS")) {                          // A/B knob: "CsxCb:ns,CsxCb:ns" overrides per shape
     char key[48];
     snprintf(key, sizeof(key), "%dx%d:", g.Cs, g.Cb);
     if (const char* q = strstr(e, key)) { const int v = atoi(q + strlen(key)); if (v > 0) return v; }
@@ -509,7 +510,7 @@ inline int gemm_nsplit(long M, long N, long K) {
   long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   if (tiles >= 128) return 1;
   long target = 384;
-  if (const char* e = getenv("VP_GEMM_BLOCKS")) target = atol(e);       // A/B knob
+  if (const char* e = VP_GETENV("VP_GEMM_BLOCKS")) target = atol(e);       // A/B knob
   long want = (target + tiles - 1) / tiles;
   long maxs = (K + 255) / 256;
   long s = want < maxs ? want : maxs;
