@@ -1,7 +1,8 @@
-"""Coordinate search over the workgroup tile of each split-bf16 conv launch shape of the FUSED VAE-GAN step (128x128, 16 images),
-in one process: VP_TILE_OVERRIDE is read per launch, candidates alternate with the incumbent (tools/search_tiles.py is the same
-for the VAE step).  A candidate that a launch rejects (statistics workspace sized for another tile) is skipped.
-usage: python tools/search_tiles_gan.py [rounds] [steps]"""
+"""Coordinate search over the workgroup tile of each split-bf16 conv launch shape of the FUSED VAE-GAN step (128x128, 16 images) or,
+with --vae B, of the fused VAE step at B images per GPU (bench.py's batch sweep), in one process: VP_TILE_OVERRIDE is read per
+launch, candidates alternate with the incumbent (tools/search_tiles.py is the subprocess form for the VAE step at 32 images).  A
+candidate that a launch rejects (statistics workspace sized for another tile) is skipped.
+usage: python tools/search_tiles_gan.py [rounds] [steps] [--vae B]"""
 import io
 import os
 import re
@@ -15,17 +16,29 @@ os.environ.setdefault("VP_ENV_DYNAMIC", "1")      # the library then re-reads it
 
 
 def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    argv = list(sys.argv[1:])
+    vae_b = 0
+    if "--vae" in argv:
+        i = argv.index("--vae")
+        vae_b = int(argv[i + 1])
+        del argv[i:i + 2]
+    rounds = int(argv[0]) if len(argv) > 0 else 4
+    steps = int(argv[1]) if len(argv) > 1 else 20
     import vae_play_amd as V
     from vae_play_amd import optim
-    from vae_play_amd.engine_gan import FusedVAEGANStep
     torch.manual_seed(0)
-    net = V.VaeGan(128, 128).cuda().train()
-    opts = [optim.RMSprop(m.parameters(), lr=1e-4) for m in (net.encoder, net.decoder, net.discriminator, net.param_encoder)]
-    st = FusedVAEGANStep(net, opts, 16, 128, lambda_mse=1e-6)
-    args = (torch.rand(16, 1, 128, 128, device="cuda"), torch.rand(16, 3, device="cuda"), torch.randn(16, 128, device="cuda"),
-            torch.randn(16, 128, device="cuda"))
+    if vae_b:
+        from vae_play_amd.engine import FusedVAEStep
+        vae = V.VAE(128, 128, 3).cuda()
+        st = FusedVAEStep(vae, optim.Adam(vae.parameters(), lr=1e-4), vae_b, 128, 3)
+        args = (torch.rand(vae_b, 3, 128, 128, device="cuda"), torch.randn(vae_b, 128, device="cuda"))
+    else:
+        from vae_play_amd.engine_gan import FusedVAEGANStep
+        net = V.VaeGan(128, 128).cuda().train()
+        opts = [optim.RMSprop(m.parameters(), lr=1e-4) for m in (net.encoder, net.decoder, net.discriminator, net.param_encoder)]
+        st = FusedVAEGANStep(net, opts, 16, 128, lambda_mse=1e-6)
+        args = (torch.rand(16, 1, 128, 128, device="cuda"), torch.rand(16, 3, device="cuda"), torch.randn(16, 128, device="cuda"),
+                torch.randn(16, 128, device="cuda"))
     for _ in range(5):
         st.step(*args)
     torch.cuda.synchronize()
