@@ -922,7 +922,24 @@ class FusedVAEStep:
             # one rank: encoder.fc.0's weight gradient (134 MB at config 3) is contracted from its two factors inside the Adam
             # kernel instead of being written by a GEMM and read back by the update; fc.0.weight.grad is NOT written by step()
             # (forward_backward() alone materialises every gradient).
-            out = self.forward_backward(x, eps, timers, on_fc_wgrad=_noop)
+            # ... and that update runs on the side stream as soon as its factors are final and the dense input gradient has read the
+            # weight for the last time in this step: 134 us of HBM-bound work underneath the encoder's MFMA-bound convolution backward
+            # instead of behind it (VP_ADAM_OUTER_EARLY=0: at the end of the step; 1: fc.0 only; 2, the default: fc.0 and the arena
+            # slice behind it.  3.640 / 3.609 / 3.572 ms in one process, tools/ab_env.py)
+            early = None
+            if timers is None and os.environ.get("VP_ADAM_OUTER_EARLY", "2") != "0":
+                def early():
+                    side = self._side_ctx()
+                    if side is None:
+                        return
+                    side.flush()
+                    side.fork.record()
+                    side.stream.wait_event(side.fork)
+                    with torch.cuda.stream(side.stream):
+                        # (mode 2: also the arena slice behind fc.0 -- the rest of the encoder's dense layers and the whole decoder,
+                        # whose weight gradients precede this launch on the side stream and whose other gradients the fork covers)
+                        self.opt.step_outer_early(with_tail=os.environ.get("VP_ADAM_OUTER_EARLY", "2") == "2")
+            out = self.forward_backward(x, eps, timers, on_fc_wgrad=_noop, on_dense_grads=early)
             self.opt.step(outer=True)
             return out
         else:

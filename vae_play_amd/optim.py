@@ -16,7 +16,7 @@ from typing import Iterable, List
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 _ALIGN = 64  # floats (256 B)
 
@@ -206,20 +206,46 @@ class Adam(_FlatOptimizer):
         self._outer = (off, (param.numel() + 63) // 64 * 64, R, Cn, A, Bm)
 
     @torch.no_grad()
+    def step_outer_early(self, with_tail: bool = False) -> None:
+        """The factored parameter's update of the step that ``step(outer=True)`` will complete, launched NOW on the current stream
+        (the fused engine: on its side stream, as soon as both factors are final and the weight has been read for the last time in
+        this step, underneath the rest of backward).  ``with_tail``: also the arena slice behind that parameter (the caller
+        guarantees that its gradients are final and its parameters no longer read).  ``step(outer=True)`` skips what ran here."""
+        off, span, R, Cn, A, Bm = self._outer
+        n = R * Cn
+        a = self.arena
+        ops.PARAM_EPOCH[0] += 1
+        ops.adam_outer_step(a.flat_param[off:off + n].view(R, Cn), self.exp_avg[off:off + n].view(R, Cn),
+                            self.exp_avg_sq[off:off + n].view(R, Cn), A, Bm, self.lr, self.betas[0], self.betas[1], self.eps,
+                            self.step_count + 1, self.grad_scale)
+        if with_tail:
+            lo, hi = off + span, a.flat_param.numel()
+            if hi > lo:
+                ops.adam_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
+                              self.betas[0], self.betas[1], self.eps, self.step_count + 1, self.grad_scale)
+        self._outer_early_done = 2 if with_tail else 1
+
+    @torch.no_grad()
     def step(self, outer: bool = False) -> None:
         self.step_count += 1
         ops.PARAM_EPOCH[0] += 1
         a = self.arena
+        early = getattr(self, "_outer_early_done", 0)
+        self._outer_early_done = 0
+        if early and not (outer and getattr(self, "_outer", None) is not None):
+            raise _lib.VaePlayHipError("step_outer_early() must be followed by step(outer=True)")
         if a.numel:
             a.gather_grads()
             if outer and getattr(self, "_outer", None) is not None:
                 off, span, R, Cn, A, Bm = self._outer
                 n = R * Cn
                 self.step_range(0, off)
-                ops.adam_outer_step(a.flat_param[off:off + n].view(R, Cn), self.exp_avg[off:off + n].view(R, Cn),
-                                    self.exp_avg_sq[off:off + n].view(R, Cn), A, Bm, self.lr, self.betas[0], self.betas[1], self.eps,
-                                    self.step_count, self.grad_scale)
-                self.step_range(off + span, a.flat_param.numel())
+                if not early:
+                    ops.adam_outer_step(a.flat_param[off:off + n].view(R, Cn), self.exp_avg[off:off + n].view(R, Cn),
+                                        self.exp_avg_sq[off:off + n].view(R, Cn), A, Bm, self.lr, self.betas[0], self.betas[1], self.eps,
+                                        self.step_count, self.grad_scale)
+                if early < 2:
+                    self.step_range(off + span, a.flat_param.numel())
             else:
                 ops.adam_step(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                               self.eps, self.step_count, self.grad_scale)
