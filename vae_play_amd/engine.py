@@ -56,10 +56,18 @@ class _Plan:
     def wait_side(self, k: int):
         self.calls.append(["__wait_side__", None, [k], 0, 0.0, "", None])
 
-    def run(self, stream_ptr: int, timers: Optional[dict] = None, start: int = 0, stop: Optional[int] = None, side=None):
+    def hook(self, key: str):
+        """A named point of the plan: ``run(..., hooks={key: fn})`` calls ``fn(side)`` there (between two launches)."""
+        self.calls.append(["__hook__", None, [key], 0, 0.0, "", None])
+
+    def run(self, stream_ptr: int, timers: Optional[dict] = None, start: int = 0, stop: Optional[int] = None, side=None, hooks=None):
         """``side`` = a ``_SideCtx`` (side stream, its events, the fork event) or None (everything on the main stream)."""
         s = c_void_p(stream_ptr)
         for ci, (name, fn, a, slot, flops, tag, sev) in enumerate(self.calls[start:stop], start):
+            if name == "__hook__":
+                if hooks is not None and a[0] in hooks:
+                    hooks[a[0]](side)
+                continue
             if fn is None:                                   # main stream waits for a side event
                 if side is not None:
                     side.flush_if_pending(a[0])              # (an event that was never recorded would not be waited for)

@@ -122,6 +122,15 @@ class FusedVAEGANStep:
             raise _lib.VaePlayHipError("the decoder's parameters must live in one arena")
         self._dec_arena = dec_arena
         self._dec_shadow = torch.zeros_like(dec_arena.flat_grad)
+        # optimisers whose arena holds exactly one sub-network's parameters (train.py:212-219 builds one optimiser per sub-network):
+        # candidates for an early update; an arena shared between sub-networks is updated at the end of the step
+        self._arena_opts = {"disc": [], "dec": []}
+        for kind, mod in (("disc", net.discriminator), ("dec", dec)):
+            ids = {id(p) for p in mod.parameters()}
+            for o in self.opts:
+                if o.arena.numel and {id(p) for p in o.arena.params} == ids and not getattr(o.arena, "foreign", None):
+                    self._arena_opts[kind].append(o)
+        self._early_done = set()
 
         def grad2_of(p):         # second decoder pass: same offsets in the shadow arena
             return self._dec_shadow[p._vp_off:p._vp_off + p.numel()].view_as(p)
@@ -472,6 +481,7 @@ class FusedVAEGANStep:
         dxc = self._buf("g.dxcat", 2 * n_pix)                       # d x_tilde | d x_p from the discriminator
         bwd.add("vp_conv5_smallout_bf16x3", at(gA, B * S * S * C0), P(self._wf), None, P(dxc), 2 * B, S, S, C0, 1, _ACT_NONE,
                 flops=50.0 * 2 * B * S * S * C0, tag="disc0.dgrad")
+        bwd.hook("disc_done")       # every discriminator gradient is launched and none of its parameters is read again in this step
 
         # ---- decoder ----
         def dec_bwd(rec, dout, gfn, dz):
@@ -541,6 +551,7 @@ class FusedVAEGANStep:
         bwd.add("vp_add_f32", P(dxt), P(dxc), P(dxt), n_pix)
         dz_dec = self._buf("g.dz_dec", B * Z)
         dec_bwd(dec1, P(dxt), grad_of, dz_dec)
+        bwd.hook("dec_done")        # both decoder passes' gradients are launched; the decoder's parameters are not read again
         dz = self._buf("g.dz", B * Z)
         bwd.add("vp_add_f32", P(dz_dec), P(dz_pe), P(dz), B * Z)
 
@@ -592,7 +603,8 @@ class FusedVAEGANStep:
         return self._side
 
     @torch.no_grad()
-    def forward_backward(self, x: torch.Tensor, targets: torch.Tensor, eps: torch.Tensor, z_p: torch.Tensor, timers: Optional[dict] = None):
+    def forward_backward(self, x: torch.Tensor, targets: torch.Tensor, eps: torch.Tensor, z_p: torch.Tensor, timers: Optional[dict] = None,
+                         early_updates: bool = False):
         """Gradients of the summed losses of train.py:61-73 land in the four optimisers' flat gradient arenas.  ``eps`` is the
         reparameterisation noise (models/networks.py:230), ``z_p`` the prior sample (:240).  Outputs (static buffers, overwritten
         by the next step): ``x_tilde``, ``x_p``, ``mu``, ``logvar``, ``disc_class``, ``kl``, ``mse``, ``bce_sums``, ``l1``,
@@ -614,17 +626,41 @@ class FusedVAEGANStep:
         m = float(self._disc_replay[0].momentum)
         torch._foreach_mul_(self._running, 2.0 - m)
         torch._foreach_add_(self._running, self._snap, alpha=-(1.0 - m))
-        self._bwd.run(s, timers, side=side)
+        self._early_done = set()
+        hooks = None
+        if early_updates and side is not None:
+            # RMSprop of an arena as soon as its gradients are launched, ON THE SIDE STREAM (behind that arena's weight gradients, which
+            # run there; the fork covers the gradients the main stream produced): HBM-bound updates underneath the MFMA-bound backward
+            # of the networks that are still to come instead of behind the whole step
+            def early(kind):
+                def fn(sd):
+                    sd.flush()
+                    sd.fork.record()
+                    sd.stream.wait_event(sd.fork)
+                    with torch.cuda.stream(sd.stream):
+                        if kind == "dec":
+                            a = self._dec_arena
+                            _lib.call("vp_add_f32", _ptr(a.flat_grad), _ptr(self._dec_shadow), _ptr(a.flat_grad), a.flat_grad.numel(),
+                                      c_void_p(sd.stream.cuda_stream))
+                        for o in self._arena_opts[kind]:
+                            o.begin_step()
+                            o.step_range(0, o.arena.flat_param.numel())
+                            self._early_done.add(id(o))
+                return fn
+            hooks = {"disc_done": early("disc"), "dec_done": early("dec")}
+        self._bwd.run(s, timers, side=side, hooks=hooks)
         if side is not None:
             side.flush()
             torch.cuda.current_stream().wait_stream(side[0])
-        a = self._dec_arena
-        _lib.call("vp_add_f32", _ptr(a.flat_grad), _ptr(self._dec_shadow), _ptr(a.flat_grad), a.flat_grad.numel(), c_void_p(s))
+        if not any(id(o) in self._early_done for o in self._arena_opts["dec"]):
+            a = self._dec_arena
+            _lib.call("vp_add_f32", _ptr(a.flat_grad), _ptr(self._dec_shadow), _ptr(a.flat_grad), a.flat_grad.numel(), c_void_p(s))
         self._steps_since_sync += 1
 
     def step(self, x, targets, eps, z_p, timers: Optional[dict] = None):
         """One training iteration of train.py:43-78: forward, losses, backward, gradient all-reduce (several ranks), four RMSprop updates."""
-        self.forward_backward(x, targets, eps, z_p, timers)
+        early = (not parallel.dp_active(self.group)) and timers is None and os.environ.get("VP_GAN_EARLY_UPDATES", "1") != "0"
+        self.forward_backward(x, targets, eps, z_p, timers, early_updates=early)
         arenas = []
         for o in self.opts:
             if o.arena.numel and all(o.arena is not q for q in arenas):
@@ -635,6 +671,8 @@ class FusedVAEGANStep:
                 if w is not None:
                     w.wait()
         for o in self.opts:
+            if id(o) in self._early_done:      # updated on the side stream during backward (forward_backward's hooks)
+                continue
             o.begin_step()
             o.step_range(0, o.arena.flat_param.numel() if o.arena.numel else 0)
 
