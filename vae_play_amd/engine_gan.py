@@ -634,6 +634,8 @@ class FusedVAEGANStep:
             # of the networks that are still to come instead of behind the whole step
             def early(kind):
                 def fn(sd):
+                    if not self._arena_opts[kind]:          # (an arena shared between sub-networks: updated at the end of the step)
+                        return
                     sd.flush()
                     sd.fork.record()
                     sd.stream.wait_event(sd.fork)
