@@ -946,7 +946,8 @@ class FusedVAEStep:
                     with torch.cuda.stream(side.stream):
                         # (mode 2: also the arena slice behind fc.0 -- the rest of the encoder's dense layers and the whole decoder,
                         # whose weight gradients precede this launch on the side stream and whose other gradients the fork covers)
-                        self.opt.step_outer_early(with_tail=os.environ.get("VP_ADAM_OUTER_EARLY", "2") == "2")
+                        self.opt.step_outer_early(with_tail=(os.environ.get("VP_ADAM_OUTER_EARLY", "2") == "2"
+                                                             and getattr(self, "_early_tail_ok", False)))
             out = self.forward_backward(x, eps, timers, on_fc_wgrad=_noop, on_dense_grads=early)
             self.opt.step(outer=True)
             return out
@@ -962,6 +963,12 @@ class FusedVAEStep:
         if getattr(self.opt, "_outer", None) is None:
             dh, flat, fcw, F0 = self._fc_factors
             self.opt.set_outer_grad(fcw, dh.view(self.B, 1024), flat.view(self.B, F0))
+            # the early update of the arena slice BEHIND fc.0 (step()) relies on the arena order of vae.parameters(): encoder conv
+            # blocks, fc.0, the encoder's other dense layers, the decoder
+            try:
+                self._early_tail_ok = self._encoder_dense_start() == self.opt._outer[0]
+            except AssertionError:
+                self._early_tail_ok = False
         return True
 
     def capture(self, warmup: int = 2):
