@@ -131,6 +131,18 @@ class FusedVAEGANStep:
                 if o.arena.numel and {id(p) for p in o.arena.params} == ids and not getattr(o.arena, "foreign", None):
                     self._arena_opts[kind].append(o)
         self._early_done = set()
+        # the encoder's arena: conv blocks first, then fc.0 / fc.1 / l_mu / l_var (Encoder's parameter order); the dense slice -- 90 % of
+        # it -- can be updated as soon as the dense backward is through, the conv slice only at the end of the step
+        self._enc_dense = []
+        enc_ids = {id(p) for p in enc.parameters()}
+        conv_ids = {id(p) for p in enc.conv.parameters()}
+        for o in self.opts:
+            a = o.arena
+            if a.numel and {id(p) for p in a.params} == enc_ids and not getattr(a, "foreign", None):
+                lo = min(off for p, off in zip(a.params, a.offsets) if id(p) not in conv_ids)
+                if all((id(p) in conv_ids) == (off < lo) for p, off in zip(a.params, a.offsets)):
+                    self._enc_dense.append((o, lo))
+        self._early_partial = {}
 
         def grad2_of(p):         # second decoder pass: same offsets in the shadow arena
             return self._dec_shadow[p._vp_off:p._vp_off + p.numel()].view_as(p)
@@ -568,6 +580,7 @@ class FusedVAEGANStep:
         bn_bwd(h, dhb_a, g_eh, None, B, H1, fc_bn, h_mean, h_rstd, h_ws, grad_of)
         lin_wgrad(bwd, g_eh, flat, grad_of(fc_lin.weight), B, H1, F0)
         lin_dgrad(bwd, g_eh, fc_lin.weight, hA, B, H1, F0)
+        bwd.hook("enc_dense_done")  # the encoder's dense gradients (fc, l_mu, l_var) are launched, their parameters not read again
         bwd.add("vp_nchw_to_nhwc_f32", P(hA), P(hB), B, size, 8, 8)
         for i in range(L - 1, 0, -1):
             gather_block_bwd(enc_rec[i], B, hB, grad_of, True, f"enc{i}")
@@ -627,6 +640,7 @@ class FusedVAEGANStep:
         torch._foreach_mul_(self._running, 2.0 - m)
         torch._foreach_add_(self._running, self._snap, alpha=-(1.0 - m))
         self._early_done = set()
+        self._early_partial = {}
         hooks = None
         if early_updates and side is not None:
             # RMSprop of an arena as soon as its gradients are launched, ON THE SIDE STREAM (behind that arena's weight gradients, which
@@ -649,7 +663,18 @@ class FusedVAEGANStep:
                             o.step_range(0, o.arena.flat_param.numel())
                             self._early_done.add(id(o))
                 return fn
-            hooks = {"disc_done": early("disc"), "dec_done": early("dec")}
+            def early_enc_dense(sd):
+                if not self._enc_dense:
+                    return
+                sd.flush()
+                sd.fork.record()
+                sd.stream.wait_event(sd.fork)
+                with torch.cuda.stream(sd.stream):
+                    for o, lo in self._enc_dense:
+                        o.begin_step()
+                        o.step_range(lo, o.arena.flat_param.numel())
+                        self._early_partial[id(o)] = lo
+            hooks = {"disc_done": early("disc"), "dec_done": early("dec"), "enc_dense_done": early_enc_dense}
         self._bwd.run(s, timers, side=side, hooks=hooks)
         if side is not None:
             side.flush()
@@ -674,6 +699,9 @@ class FusedVAEGANStep:
                     w.wait()
         for o in self.opts:
             if id(o) in self._early_done:      # updated on the side stream during backward (forward_backward's hooks)
+                continue
+            if id(o) in self._early_partial:   # its dense slice was: the rest now, same step count
+                o.step_range(0, self._early_partial[id(o)])
                 continue
             o.begin_step()
             o.step_range(0, o.arena.flat_param.numel() if o.arena.numel else 0)
