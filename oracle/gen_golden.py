@@ -37,11 +37,22 @@ torch.set_flush_denormal(False)
 def import_reference():
     if not os.path.isdir(REF):
         raise SystemExit(f"reference checkout not found at {REF}")
-    sys.path.insert(0, REF)
-    import importlib
-    nets = importlib.import_module("models.networks")
-    blocks = importlib.import_module("models.blocks")
-    sys.path.remove(REF)
+    # this repository has a top-level ``models`` package of its own (import-path aliases of the drop-ins), and the reference's
+    # ``models/`` has no __init__.py (a namespace package, which a regular package of the same name shadows whatever the
+    # sys.path order): load the two reference files BY PATH under private names.  Both import only torch / numpy / math.
+    import importlib.util
+
+    def load(private_name, rel):
+        path = os.path.join(REF, rel)
+        spec = importlib.util.spec_from_file_location(private_name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if not os.path.realpath(mod.__file__).startswith(os.path.realpath(REF) + os.sep):
+            raise SystemExit(f"{private_name} resolved to {mod.__file__}, not to the reference checkout {REF}")
+        return mod
+
+    nets = load("_ref_models_networks", os.path.join("models", "networks.py"))
+    blocks = load("_ref_models_blocks", os.path.join("models", "blocks.py"))
     return nets, blocks
 
 

@@ -301,7 +301,13 @@ size_t vp_conv_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Hb, int W
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
   int ns = wgrad_nsplit(g);
   if (wgrad_pair_applicable(g)) ns = wgrad_pair_nsplit(g, ns);   // tap pairs split twice as deep
-  return wgrad_slab_floats(g, ns) * sizeof(float);
+  size_t n = wgrad_slab_floats(g, ns);
+  if (const int bn = wgrad5_kind(g)) {                           // rows of taps: one slab set per CU-filling round
+    int kper = 0;
+    const size_t n5 = wgrad5_slab_floats(g, bn, wgrad5_nsplit(g, bn, &kper));
+    if (n5 > n) n = n5;
+  }
+  return n * sizeof(float);
 }
 
 int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,

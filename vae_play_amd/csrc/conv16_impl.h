@@ -5,6 +5,7 @@
 #include <type_traits>
 #include "common.h"
 #include "igemm16p.h"
+#include "wgrad5.h"
 #include "halo.h"
 #include "narrow.h"
 #include "split.h"
@@ -208,6 +209,26 @@ static int wgrad16_wide(int kind, const void* big_split, const void* small_split
   return slab_reduce_launch((const float*)ws, dw_ref, g.Cs, g.Cb, ns, s, g.nt);
 }
 
+// Row-of-taps weight gradient (wgrad5.h): the plain 5x5 stride-2 layers with 128 | Cs and Cb = 64 or 128 | Cb -- every block of the
+// VAE / VAE-GAN except the 3-channel edge layers.  A/B knob VP_WGRAD5=0 sends them back to the one-tap-per-workgroup kernels.
+static inline int wgrad5_kind(const ConvGeom& g) {
+  static const bool on = !(getenv("VP_WGRAD5") && atoi(getenv("VP_WGRAD5")) == 0);
+  return on ? wgrad5_bn(g) : 0;
+}
+
+template <int MODE>
+static int wgrad16_rows(int bn, const void* big_split, const void* small_split, float* dw_ref, const ConvGeom& g, void* ws, size_t ws_bytes,
+                        vp_stream stream, float alpha) {
+  int kper = 0;
+  const int ns = wgrad5_nsplit(g, bn, &kper);
+  if (ws_bytes < wgrad5_slab_floats(g, bn, ns) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv_wgrad_bf16x3: workspace too small");
+  int slabs = 0;
+  wgrad5_launch<MODE>(big_split, small_split, (float*)ws, g, bn, ns, kper, alpha, (hipStream_t)stream, &slabs);
+  int rc = check_launch("vp_conv_wgrad_bf16x3(rows of taps)");
+  if (rc) return rc;
+  return slab_reduce_launch((const float*)ws, dw_ref, g.Cs, g.Cb, slabs, (hipStream_t)stream, g.nt);
+}
+
 template <class PW>
 static int wgrad16_t(const void* big_split, const void* small_split, float* dw_ref, const ConvGeom& g, int ns, void* ws, vp_stream stream,
                      float alpha = 1.f) {
@@ -319,6 +340,14 @@ static int wgrad16(const void* big_split, const void* small_split, float* dw_ref
   VP_REQUIRE(stride == 1 || stride == 2, "vp_conv_wgrad_bf16x3: stride must be 1 or 2");
   VP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "vp_conv_wgrad_bf16x3: kernel size must be 1, 3 or 5");
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  if (const int bn = wgrad5_kind(g)) {
+    if constexpr (F16 != 0) {
+      VP_REQUIRE(alpha > 0.f, "vp_conv_wgrad_f16x2: out_scale must be positive");
+      return wgrad16_rows<1>(bn, big_split, small_split, dw_ref, g, ws, ws_bytes, stream, alpha);
+    } else {
+      return wgrad16_rows<0>(bn, big_split, small_split, dw_ref, g, ws, ws_bytes, stream, 1.f);
+    }
+  }
   const int ns = wgrad_nsplit(g);
   if (ws_bytes < wgrad_slab_floats(g, ns) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv_wgrad_bf16x3: workspace too small");
   const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;

@@ -782,6 +782,9 @@ class FusedVAEStep:
             self._graph.replay()
         else:
             self._launch_all(timers, on_decoder_grads, on_dense_grads, on_fc_wgrad, after_forward, on_encoder_tail)
+        # the plan wrote every gradient into the arena: a ``.grad`` left None by zero_grad(set_to_none=True) must not read as
+        # "no gradient" in the optimiser's gather_grads()
+        self.opt.arena.adopt_views()
         # BatchNorm num_batches_tracked is advanced lazily in sync_counters()
         self._steps_since_sync = getattr(self, "_steps_since_sync", 0) + 1
         return self._loss_num, self.recon, self.kl_sum     # (loss per image, recon sum, KL sum): device scalars of the plan
@@ -802,6 +805,12 @@ class FusedVAEStep:
                                     if a.value == v:
                                         self._in_slots[k].append((call[2], i))
         for key, t, static in (("x", x, self.x_nchw), ("eps", eps, self.eps)):
+            if tuple(t.shape) != tuple(static.shape):
+                # (``static.copy_(t)`` would broadcast a (1, C, H, W) batch silently; a DataLoader's short last batch -- no
+                # drop_last -- would raise a bare torch broadcast error)
+                raise _lib.VaePlayHipError(
+                    f"FusedVAEStep: {key} has shape {tuple(t.shape)}, this plan was built for {tuple(static.shape)} "
+                    f"(batch {self.B}; build a second FusedVAEStep over the same optimiser for another batch size)")
             slots = self._in_slots[key]
             direct = (bool(slots) and self._graph is None and t.device == static.device and t.dtype == torch.float32
                       and t.is_contiguous() and t.shape == static.shape)
@@ -908,7 +917,7 @@ class FusedVAEStep:
                     w2 = parallel.allgather_rows(dh_all, dh.view(B, 1024), self.group, async_op=True)
                     for w in gather + [w2]:
                         w.wait()
-                    ops.gemm(dh_all, 1, 1024, flat_all, 1, F0, 1024, F0, W * B, 2, out=fcw.grad.view(1024, F0))
+                    ops.gemm(dh_all, 1, 1024, flat_all, 1, F0, 1024, F0, W * B, 2, out=self.opt.arena.grad_view(fcw).view(1024, F0))
 
                 def dense_bucket():
                     assert fc_lo == dense, "fc.0.weight must open the encoder's dense slice"
@@ -960,9 +969,14 @@ class FusedVAEStep:
     def _outer_adam(self) -> bool:
         if os.environ.get("VP_ADAM_OUTER", "1") == "0" or not hasattr(self.opt, "set_outer_grad"):
             return False
-        if getattr(self.opt, "_outer", None) is None:
-            dh, flat, fcw, F0 = self._fc_factors
+        # the factors are THIS engine's static buffers: bind them on every call in which the optimiser holds another engine's
+        # (a second FusedVAEStep over the same optimiser -- another batch size, precision or a rebuilt plan -- would otherwise
+        # have its fc.0 update contracted from the first engine's stale buffers)
+        dh, flat, fcw, F0 = self._fc_factors
+        cur = getattr(self.opt, "_outer", None)
+        if cur is None or cur[4].data_ptr() != dh.data_ptr() or cur[5].data_ptr() != flat.data_ptr() or cur[4].shape[0] != self.B:
             self.opt.set_outer_grad(fcw, dh.view(self.B, 1024), flat.view(self.B, F0))
+        if not hasattr(self, "_early_tail_ok"):
             # the early update of the arena slice BEHIND fc.0 (step()) relies on the arena order of vae.parameters(): encoder conv
             # blocks, fc.0, the encoder's other dense layers, the decoder
             try:

@@ -682,6 +682,8 @@ class FusedVAEGANStep:
         if not any(id(o) in self._early_done for o in self._arena_opts["dec"]):
             a = self._dec_arena
             _lib.call("vp_add_f32", _ptr(a.flat_grad), _ptr(self._dec_shadow), _ptr(a.flat_grad), a.flat_grad.numel(), c_void_p(s))
+        for o in self.opts:        # the plan wrote the arenas: a ``.grad`` left None by module.zero_grad() must not read as "no gradient"
+            o.arena.adopt_views()
         self._steps_since_sync += 1
 
     def step(self, x, targets, eps, z_p, timers: Optional[dict] = None):

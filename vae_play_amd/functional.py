@@ -79,26 +79,35 @@ def _grad_out(param) -> Optional[torch.Tensor]:
 _DIRECT_GRADS = os.environ.get("VP_DIRECT_GRADS", "1") != "0"
 
 
-_PACKED = {}     # (id(weight), layout) -> (weight, weight._version, optimiser epoch, packed tensor)
+_PACKED = {}     # (id(weight), layout) -> (weakref(weight), weight._version, optimiser epoch, data_ptr, device, packed tensor)
+
+
+def _evict_packed(wid: int) -> None:
+    for k in [k for k in _PACKED if k[0] == wid]:
+        _PACKED.pop(k, None)
 
 
 def _packed(fn, weight, want_p1: bool):
     """``fn(weight, want_p0, want_p1)`` (an ops.pack_* re-layout of a conv weight) through a cache: a layer that runs several times
     per step -- the VAE-GAN's decoder decodes z and z_p, its discriminator sees both -- packs each layout once per weight VALUE.
     Valid while neither torch (``_version``) nor a flat-arena optimiser (ops.PARAM_EPOCH: its kernels update the weights behind
-    torch's back) has changed the parameter; only leaf parameters are cached."""
+    torch's back) has changed the parameter and its storage is where it was (``module.to()`` / ``.float()`` re-point ``.data``
+    without bumping the version); only leaf parameters are cached, and an entry dies with its parameter (weakref.finalize).
+    Writes through ``p.data`` that keep the storage (``p.data.mul_()``, ``dist.broadcast(p.data)``) bump neither counter: follow them
+    with ``ops.PARAM_EPOCH[0] += 1``."""
     if not (isinstance(weight, torch.nn.Parameter) and _PACK_CACHE_ON):
         r = fn(weight, not want_p1, want_p1)
         return r[1] if want_p1 else r[0]
     key = (id(weight), fn.__name__, want_p1, _PRECISION)
     hit = _PACKED.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == ops.PARAM_EPOCH[0]:
-        return hit[3]
+    if (hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == ops.PARAM_EPOCH[0]
+            and hit[3] == weight.data_ptr() and hit[4] == weight.device):
+        return hit[5]
     r = fn(weight, not want_p1, want_p1)
     t = r[1] if want_p1 else r[0]
-    if len(_PACKED) > 4096:          # ids of dead parameters (models built and dropped, e.g. by a test session)
-        _PACKED.clear()
-    _PACKED[key] = (weakref.ref(weight), weight._version, ops.PARAM_EPOCH[0], t)
+    if not any(k[0] == id(weight) for k in _PACKED):      # first entry of this parameter: drop its entries when it dies
+        weakref.finalize(weight, _evict_packed, id(weight))
+    _PACKED[key] = (weakref.ref(weight), weight._version, ops.PARAM_EPOCH[0], weight.data_ptr(), weight.device, t)
     return t
 
 

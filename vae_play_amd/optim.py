@@ -82,6 +82,16 @@ class FlatArena:
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
 
+    def adopt_views(self) -> None:
+        """Re-point every ``.grad`` that is None at its arena slice WITHOUT touching the slice: the fused plans (engine.py,
+        engine_gan.py) write gradients straight into the arena, so after ``optimizer.zero_grad(set_to_none=True)`` or the
+        reference's ``module.zero_grad()`` (train.py:68) the slices hold this step's gradients although ``.grad`` is None --
+        ``gather_grads()`` would otherwise take "None" for "received no gradient" and zero-fill them before the update."""
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None:
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+                p._vp_pending = False
+
     def gather_grads(self) -> None:
         """Bring gradients that live outside the arena back into it.  ``module.zero_grad()`` (train.py:68) sets
         ``.grad`` to None, after which autograd allocates fresh tensors: copy those in and re-point ``.grad``.
