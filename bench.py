@@ -206,12 +206,16 @@ def measure(fused, x, eps, steps, untimed, world, graph, overlap=True, tags_out=
         torch.cuda.synchronize()
 
     inst = sorted({0, steps // 2})[:N_INST] if timers is not None else []
+    trace = None
+    if world > 1 and timers is not None:      # several ranks: the instrumented steps also trace their collectives (comm.buckets)
+        from vae_play_amd import parallel
+        trace = parallel.CommTrace()
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         if i in inst:
             timers["slot"] = inst.index(i)
-            loss, recon, kl = fused.step(x, eps, timers, overlap=overlap)
+            loss, recon, kl = fused.step(x, eps, timers, overlap=overlap, comm_trace=trace)
         else:
             loss, recon, kl = fused.step(x, eps, None, overlap=overlap)
     barrier()
@@ -244,7 +248,8 @@ def measure(fused, x, eps, steps, untimed, world, graph, overlap=True, tags_out=
             json.dump({k: {"ms": round(v[1] / v[2] * 1e3, 4), "gflop": round(v[0] / v[2] / 1e9, 3),
                            "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in per.items()}, f, indent=1)
     n_inst = len(inst) if measured == "timed-region" else steps
-    return {"elapsed": elapsed, "loss": final_loss, "fam": fam, "n_inst": n_inst, "measured": measured}
+    return {"elapsed": elapsed, "loss": final_loss, "fam": fam, "n_inst": n_inst, "measured": measured,
+            "comm_trace": trace.summary() if trace is not None else None}
 
 
 def roofline_of(m, steps, B, S, C, z):
@@ -273,8 +278,11 @@ def roofline_of(m, steps, B, S, C, z):
             "measured": m["measured"]}
 
 
-def comm_record(world, args):
-    """What the gradient exchange ran on (so that a multi-GPU line can be checked from the JSON alone)."""
+def comm_record(world, args, trace=None):
+    """What the gradient exchange ran on (so that a multi-GPU line can be checked from the JSON alone).  Several ranks: ``buckets``
+    = every collective of a step with its bytes and its device time (issue-ready -> result-ready on a communicator-side stream,
+    queueing behind earlier buckets included), ``exposed_ms_per_step`` = the time rank 0's main stream spent waiting for
+    collectives, both from the instrumented steps of the timed region (serial kernel schedule, like the roofline events)."""
     rec = {"backend": None, "world_size_seen": 1, "rccl_version": None, "exchange": "none (one rank)"}
     try:
         v = torch.cuda.nccl.version()
@@ -294,6 +302,11 @@ def comm_record(world, args):
                                + ("; encoder.fc.0 weight gradient exchanged as its two factors (2 all-gathers) and contracted locally"
                                   if factored else ""))
         rec["dp_factored"], rec["dp_enc_tail"], rec["dp_overlap"] = factored, tail, bool(args.dp_overlap)
+        if trace is not None:
+            rec.update(trace)
+            n_ar = trace["collectives_per_step"].get("all_reduce", 0)
+            rec["all_reduces_per_step"] = n_ar
+            rec["all_gathers_per_step"] = trace["collectives_per_step"].get("all_gather", 0)
     return rec
 
 
@@ -346,7 +359,7 @@ def main():
             "step_algorithmic_tflops_per_gpu": round(ips / world * STEP_GFLOP.get(S, 0.0) / 1e3, 1),
             "loss": round(m["loss"], 4),
             "roofline": roofline_of(m, args.steps, B, S, C, z),
-            "comm": comm_record(world, args),
+            "comm": comm_record(world, args, m.get("comm_trace")),
         }
     # ---- variants: one GPU only (their collectives would have to match on every rank), after the headline ----------------
     if world == 1 and not args.no_variants:
@@ -379,6 +392,13 @@ def main():
             except Exception as ex:          # a variant must never take the headline line down with it
                 variants.append({"workload": f"{s2}x{s2}x{c2} z{z2} B{b2}", "precision": prec, "error": repr(ex)[:200]})
         out["variants"] = variants
+        # the reference-width leg at top level: the like-for-like figure against the reference's fp32 arithmetic
+        for v in variants:
+            if v.get("precision") == "f32" and v.get("batch_per_gpu") == B and "error" not in v and v["workload"].startswith(f"{S}x{S}x{C} "):
+                out["exact_f32"] = {"ms_per_step": v["ms_per_step"], "images_per_sec": v["images_per_sec"],
+                                    "step_algorithmic_tflops": v["step_algorithmic_tflops"], "roofline": v["roofline"],
+                                    "dtype": "f32 (v_mfma_f32_32x32x2_f32 / 16x16x4: exact fp32 products, fp32 accumulate)"}
+                break
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -25,6 +25,7 @@ def main():
     x, eps = torch.rand(32, 3, 128, 128, device="cuda"), torch.randn(32, 128, device="cuda")
     for v in (va, vb):
         os.environ[var] = v
+        st.reload_switches()
         for _ in range(5):
             st.step(x, eps)
     torch.cuda.synchronize()
@@ -32,6 +33,7 @@ def main():
     for _ in range(rounds):
         for v in (va, vb):
             os.environ[var] = v
+            st.reload_switches()          # the engine resolves its step-level switches when built, not per step
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):

@@ -104,6 +104,7 @@ int main(int argc, char** argv) {
   const bool want_clock = atoi(arg(argc, argv, "clock", "0")) != 0;
   const bool want_old = atoi(arg(argc, argv, "old", "1")) != 0;
   const int check = atoi(arg(argc, argv, "check", "1"));
+  const bool want_m16 = atoi(arg(argc, argv, "m16", "1")) != 0;
   CK(hipMalloc(&g_zero, 4096)); CK(hipMemset(g_zero, 0, 4096));
 
   std::vector<Layer> layers;
@@ -162,7 +163,8 @@ int main(int argc, char** argv) {
       ns_new = wgrad5_nsplit(g, bn, &kper);
       CK(hipMalloc(&slab_new, wgrad5_slab_floats(g, bn, ns_new) * 4));
     }
-    auto run_new = [&](unsigned long long* d) { wgrad5_launch<0>(big, small, slab_new, g, bn, ns_new, kper, 1.f, 0, &slabs_new, d); };
+    bool m16 = false;
+    auto run_new = [&](unsigned long long* d) { wgrad5_launch<0>(big, small, slab_new, g, bn, ns_new, kper, 1.f, 0, &slabs_new, d, m16); };
 
     printf("%-5s Cs=%-3d Cb=%-3d K=%-6zu %5.1f GF |", ly.name.c_str(), Cs, Cb, K, gflop);
     float us_old = 0;
@@ -172,7 +174,9 @@ int main(int argc, char** argv) {
       us_old = time_it(run_old, reps);
       printf(" old ns=%-2d slab %5.1f MB %6.1f us %5.1f TF |", ns_old, ns_old * per * 4e-6, us_old, gflop / us_old * 1e3);
     }
-    if (bn) {
+    for (int variant = 0; bn && variant < (bn == 128 && want_m16 ? 2 : 1); ++variant) {
+      m16 = variant == 1;
+      if (m16) printf("\n%-5s %40s |", "", "16x16x32 form");
       CK(hipMemset(slab_new, 0xff, wgrad5_slab_floats(g, bn, ns_new) * 4));
       run_new(nullptr);
       CK(hipDeviceSynchronize());
@@ -227,9 +231,8 @@ int main(int argc, char** argv) {
         rms = sqrt(rms / NSAMP);
         printf(" | vs fp64 (%d samples): max|d|/rms = %.2e%s", NSAMP, worst / rms, worst / rms > 1e-4 ? " !!!" : "");
       }
-    } else {
-      printf(" new: shape not taken");
     }
+    if (!bn) printf(" new: shape not taken");
     printf("\n");
     fflush(stdout);
     CK(hipFree(small)); CK(hipFree(big)); CK(hipFree(slab_old));

@@ -2,8 +2,19 @@
 #include "common.h"
 #include "igemm.h"
 #include "narrow.h"
+#include "conv32.h"
+#include "wgrad5.h"
 
 namespace vp {
+
+// Row-of-taps weight gradient in exact fp32 (wgrad5.h: wgrad5f_kernel): the plain 5x5 stride-2 layers with 128 | Cs and
+// Cb = 64 or 128 | Cb.  A/B knob VP_WGRAD5F=0 sends them back to igemm_kernel<ProbW>.
+static int wgrad5f_kind(const ConvGeom& g, const float* big, const float* small) {
+  const char* e = VP_GETENV("VP_WGRAD5F");
+  if (e && atoi(e) == 0) return 0;
+  if ((((uintptr_t)big | (uintptr_t)small) & 15) != 0) return 0;
+  return wgrad5_bn(g);
+}
 
 }  // namespace vp
 
@@ -41,6 +52,7 @@ int vp_conv_gather_f32(const float* big, const float* w_p0, const float* bias, f
   VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_SIGMOID, "vp_conv_gather_f32: epilogue supports none|sigmoid");
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
   if (narrow_gather_applicable(g, act)) return narrow_gather_launch(big, w_p0, bias, small_out, g, act, (hipStream_t)stream);
+  if (f32_fast_gather_ok(g, big, w_p0, act)) return f32_fast_gather(big, w_p0, bias, small_out, g, act, (hipStream_t)stream);
   ProbF p = make_probF(big, w_p0, bias, small_out, g, act);
   launch_igemm(p, p.M, p.N, 1, (hipStream_t)stream);
   return check_launch("vp_conv_gather_f32");
@@ -52,6 +64,7 @@ int vp_conv_scatter_f32(const float* small, const float* w_p1, float* big_out, i
   int rc = conv_check("vp_conv_scatter_f32", B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride);
   if (rc) return rc;
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
+  if (f32_fast_scatter_ok(g, small, w_p1)) return f32_fast_scatter(small, w_p1, big_out, g, (hipStream_t)stream);
   ProbT p = make_probT(small, w_p1, big_out, g);
   launch_igemm(p, p.M, p.N, stride * stride, (hipStream_t)stream);
   return check_launch("vp_conv_scatter_f32");
@@ -60,7 +73,13 @@ int vp_conv_scatter_f32(const float* small, const float* w_p1, float* big_out, i
 size_t vp_conv_wgrad_workspace_bytes(int B, int Hs, int Ws, int Hb, int Wb, int Cbig, int Csmall, int ks, int stride) {
   ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, ks, Hb, Wb);
   if (narrow_wgrad_kind(g)) return narrow_wgrad_ws_floats(g) * sizeof(float);
-  return wgrad_slab_floats(g, wgrad_nsplit(g)) * sizeof(float);
+  size_t n = wgrad_slab_floats(g, wgrad_nsplit(g));
+  if (const int bn = wgrad5_bn(g)) {
+    int kper = 0;
+    const size_t n5 = wgrad5_slab_floats(g, bn, wgrad5_nsplit(g, bn, &kper, true));
+    if (n5 > n) n = n5;
+  }
+  return n * sizeof(float);
 }
 
 int vp_conv_wgrad_f32(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
@@ -72,6 +91,14 @@ int vp_conv_wgrad_f32(const float* big, const float* small, float* dw_ref, int B
   if (ws_bytes < vp_conv_wgrad_workspace_bytes(B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride))
     return fail(VP_ERR_WORKSPACE, "vp_conv_wgrad_f32: workspace too small");
   if (narrow_wgrad_kind(g)) return narrow_wgrad_launch(big, small, dw_ref, g, (float*)ws, (hipStream_t)stream);
+  if (const int bn = wgrad5f_kind(g, big, small)) {
+    int kper = 0, slabs = 0;
+    const int ns5 = wgrad5_nsplit(g, bn, &kper, true);
+    wgrad5f_launch(big, small, (float*)ws, g, bn, ns5, kper, (hipStream_t)stream, &slabs);
+    rc = check_launch("vp_conv_wgrad_f32(rows of taps)");
+    if (rc) return rc;
+    return slab_reduce_launch((const float*)ws, dw_ref, Csmall, Cbig, slabs, (hipStream_t)stream, g.nt);
+  }
   const int ns = wgrad_nsplit(g);
   ProbW p = make_probW(big, small, (float*)ws, g, ns);
   launch_igemm(p, p.M, p.N, g.nt * ns, (hipStream_t)stream);

@@ -212,8 +212,8 @@ static int wgrad16_wide(int kind, const void* big_split, const void* small_split
 // Row-of-taps weight gradient (wgrad5.h): the plain 5x5 stride-2 layers with 128 | Cs and Cb = 64 or 128 | Cb -- every block of the
 // VAE / VAE-GAN except the 3-channel edge layers.  A/B knob VP_WGRAD5=0 sends them back to the one-tap-per-workgroup kernels.
 static inline int wgrad5_kind(const ConvGeom& g) {
-  static const bool on = !(getenv("VP_WGRAD5") && atoi(getenv("VP_WGRAD5")) == 0);
-  return on ? wgrad5_bn(g) : 0;
+  const char* e = VP_GETENV("VP_WGRAD5");
+  return (e && atoi(e) == 0) ? 0 : wgrad5_bn(g);
 }
 
 template <int MODE>

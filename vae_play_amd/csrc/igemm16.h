@@ -65,8 +65,12 @@ struct Lds16 {
 // F family on split planes: A(m=(b,hs,ws), k=(tap,c)) = big[...]; B(n, k) = wp0[n][tap][c]
 template <bool K5, int MODE_ = 0>
 struct ProbF16T {
-  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split)
-  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ != 0;
+  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split) | 3: fp32 (see F32)
+  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ == 1 || MODE_ == 2;
+  // MODE 3, exact fp32 through this kernel's data path: ONE plane per operand holding fp32 values, addressed in 16-bit units (the
+  // host doubles the gathered channel count: [pix][C] fp32 = [pix][2C] u16), a 16-B chunk = 4 floats, a 64-deep K-tile = 32 floats;
+  // every fragment pair is contracted by four v_mfma_f32_32x32x2_f32.  Gather / scatter families only.
+  static constexpr bool F32 = MODE_ == 3;
   float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
@@ -178,8 +182,12 @@ using ProbF16KH = ProbF16T<false, 2>;
 // T family on split planes (phase-decomposed transposed conv)
 template <bool K5, int MODE_ = 0>
 struct ProbT16T {
-  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split)
-  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ != 0;
+  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split) | 3: fp32 (see F32)
+  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ == 1 || MODE_ == 2;
+  // MODE 3, exact fp32 through this kernel's data path: ONE plane per operand holding fp32 values, addressed in 16-bit units (the
+  // host doubles the gathered channel count: [pix][C] fp32 = [pix][2C] u16), a 16-B chunk = 4 floats, a 64-deep K-tile = 32 floats;
+  // every fragment pair is contracted by four v_mfma_f32_32x32x2_f32.  Gather / scatter families only.
+  static constexpr bool F32 = MODE_ == 3;
   float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
@@ -304,8 +312,12 @@ using ProbT16KH = ProbT16T<false, 2>;
 template <bool K5, int MODE_ = 0, bool PAIR_ = false>
 struct ProbW16T {
   static constexpr bool PAIR = PAIR_;
-  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split)
-  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ != 0;
+  static constexpr int MODE = MODE_;  // 0: bf16 pairs, 3 MFMAs | 1: fp16 pairs, 2 MFMAs | 2: fp16 pairs, 3 MFMAs (see mfma_split) | 3: fp32 (see F32)
+  static constexpr bool X2 = MODE_ == 1, F16 = MODE_ == 1 || MODE_ == 2;
+  // MODE 3, exact fp32 through this kernel's data path: ONE plane per operand holding fp32 values, addressed in 16-bit units (the
+  // host doubles the gathered channel count: [pix][C] fp32 = [pix][2C] u16), a 16-B chunk = 4 floats, a 64-deep K-tile = 32 floats;
+  // every fragment pair is contracted by four v_mfma_f32_32x32x2_f32.  Gather / scatter families only.
+  static constexpr bool F32 = MODE_ == 3;
   float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
@@ -403,6 +415,16 @@ __device__ __forceinline__ f32x16_t mfma_split(const bf16x8_t& ah, const bf16x8_
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
   }
+  return c;
+}
+
+// MODE 3: both fragments are 4 fp32 values (k = 4 lh + j of an 8-float block, the same permutation for A and B): four
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate)
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16_t mfma_f32x4(const bf16x8_t& a, const bf16x8_t& b, f32x16_t c) {
+  const f32x4v_t af = __builtin_bit_cast(f32x4v_t, a), bf = __builtin_bit_cast(f32x4v_t, b);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], c, 0, 0, 0);
   return c;
 }
 
@@ -545,9 +567,11 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   constexpr int NA = P::A_KM ? NA_KM : NRA * CPT, NB = P::B_KM ? NB_KM : NRB * CPT;
   static_assert(NA >= 1 && NB >= 1, "staging map");
   // (the two-product fp16 mode never stages B's lo plane: its LDS image is one plane -- a third workgroup per CU on the 128x64 tiles)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * A_PLANE + (P::X2 ? 1 : 2) * B_PLANE];
+  constexpr bool A_LO = !P::F32, B_LO = !P::X2 && !P::F32;      // is the operand's lo plane staged and read?
+  static_assert(!P::F32 || (!P::A_KM && !P::B_KM), "fp32 mode: k-contiguous operands only");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(A_LO ? 2 : 1) * A_PLANE + (B_LO ? 2 : 1) * B_PLANE];
   unsigned char* As = lds;                   // [plane][...]
-  unsigned char* Bs = lds + 2 * A_PLANE;
+  unsigned char* Bs = lds + (A_LO ? 2 : 1) * A_PLANE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -614,13 +638,13 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 #pragma unroll
           for (int j = 0; j < CPH; ++j) {
             sa[i * CPT + j] = ld16(b0 + (l4 * CPH + j) * 8);
-            sa[i * CPT + CPH + j] = ld16(b1 + (l4 * CPH + j) * 8);
+            if constexpr (A_LO) sa[i * CPT + CPH + j] = ld16(b1 + (l4 * CPH + j) * 8);
           }
         } else {
 #pragma unroll
           for (int j = 0; j < CPH; ++j) {
             sa[i * CPT + j] = p.template a_load<false>(ra.r[i], k0, (l4 * CPH + j) * 8, 0, z);
-            sa[i * CPT + CPH + j] = p.template a_load<false>(ra.r[i], k0, (l4 * CPH + j) * 8, 1, z);
+            if constexpr (A_LO) sa[i * CPT + CPH + j] = p.template a_load<false>(ra.r[i], k0, (l4 * CPH + j) * 8, 1, z);
           }
         }
       }
@@ -659,13 +683,13 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 #pragma unroll
           for (int j = 0; j < CPH; ++j) {
             sb[i * CPT + j] = ld16(b0 + (l4 * CPH + j) * 8);
-            if constexpr (!P::X2) sb[i * CPT + CPH + j] = ld16(b1 + (l4 * CPH + j) * 8);      // X2: B's lo plane is never read
+            if constexpr (B_LO) sb[i * CPT + CPH + j] = ld16(b1 + (l4 * CPH + j) * 8);      // X2 / F32: B's lo plane is never read
           }
         } else {
 #pragma unroll
           for (int j = 0; j < CPH; ++j) {
             sb[i * CPT + j] = p.template b_load<false>(rb.r[i], k0, (l4 * CPH + j) * 8, 0, z);
-            if constexpr (!P::X2) sb[i * CPT + CPH + j] = p.template b_load<false>(rb.r[i], k0, (l4 * CPH + j) * 8, 1, z);
+            if constexpr (B_LO) sb[i * CPT + CPH + j] = p.template b_load<false>(rb.r[i], k0, (l4 * CPH + j) * 8, 1, z);
           }
         }
       }
@@ -716,7 +740,7 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
         for (int j = 0; j < CPH; ++j) {
           unsigned char* dst = As + (srow + RPP * i) * MKS + (l4 * CPH + j) * 16;
           *reinterpret_cast<u32x4_t*>(dst) = sa[i * CPT + j];
-          *reinterpret_cast<u32x4_t*>(dst + A_PLANE) = sa[i * CPT + CPH + j];
+          if constexpr (A_LO) *reinterpret_cast<u32x4_t*>(dst + A_PLANE) = sa[i * CPT + CPH + j];
         }
     } else {
       constexpr int V = BM / 8, TP = 256 / BKT, S = KmStride<BM>::bytes;
@@ -735,7 +759,7 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
         for (int j = 0; j < CPH; ++j) {
           unsigned char* dst = Bs + (srow + RPP * i) * MKS + (l4 * CPH + j) * 16;
           *reinterpret_cast<u32x4_t*>(dst) = sb[i * CPT + j];
-          if constexpr (!P::X2) *reinterpret_cast<u32x4_t*>(dst + B_PLANE) = sb[i * CPT + CPH + j];
+          if constexpr (B_LO) *reinterpret_cast<u32x4_t*>(dst + B_PLANE) = sb[i * CPT + CPH + j];
         }
     } else {
       constexpr int V = BN / 8, TP = 256 / BKT, S = KmStride<BN>::bytes;
@@ -776,19 +800,21 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = frag16<BM, P::A_KM, BKT>(As, arow0 + 32 * i, s, li, lh, lane);
-        al[i] = frag16<BM, P::A_KM, BKT>(As + A_PLANE, arow0 + 32 * i, s, li, lh, lane);
+        if constexpr (A_LO) al[i] = frag16<BM, P::A_KM, BKT>(As + A_PLANE, arow0 + 32 * i, s, li, lh, lane);
+        else al[i] = ah[i];
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = frag16<BN, P::B_KM, BKT>(Bs, brow0 + 32 * j, s, li, lh, lane);
-        if constexpr (P::X2) bl[j] = bh[j];      // not read by the two-product form
+        if constexpr (!B_LO) bl[j] = bh[j];      // not read by the two-product / fp32 forms
         else bl[j] = frag16<BN, P::B_KM, BKT>(Bs + B_PLANE, brow0 + 32 * j, s, li, lh, lane);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = mfma_split<P::MODE>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+          if constexpr (P::F32) acc[i][j] = mfma_f32x4(ah[i], bh[j], acc[i][j]);
+          else acc[i][j] = mfma_split<P::MODE>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
         }
     }
     __syncthreads();

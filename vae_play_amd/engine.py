@@ -188,6 +188,7 @@ class FusedVAEStep:
         self.dev = dev
         self._bufs: Dict[str, torch.Tensor] = {}
         self._graph = None
+        self.reload_switches()
         self._build()
         # BatchNorm ``num_batches_tracked`` is advanced lazily (sync_counters): make every state_dict() / checkpoint of the model
         # see the true counters
@@ -199,6 +200,17 @@ class FusedVAEStep:
             if o is not None:
                 o.sync_counters()
         self._sd_hook = vae.register_state_dict_pre_hook(_sync)
+
+    def reload_switches(self) -> None:
+        """The A/B switches that shape a STEP (as opposed to the plan, which reads its own in ``_build``) are resolved here, once,
+        when the engine is built -- not on every ``step()``.  The in-process A/B tools (tools/ab_env.py) call this again after
+        flipping an environment variable."""
+        env = os.environ.get
+        self._side_wgrad = env("VP_SIDE_WGRAD", "1") != "0"          # weight gradients on the side stream
+        self._adam_outer = env("VP_ADAM_OUTER", "1") != "0"          # one rank: fc.0's update contracted from its factors
+        self._adam_outer_early = int(env("VP_ADAM_OUTER_EARLY", "2"))  # 0 end of step | 1 fc.0 early | 2 fc.0 + the slice behind it
+        self._dp_factored = env("VP_DP_FACTORED", "1") != "0"        # several ranks: fc.0's gradient exchanged as its factors
+        self._dp_enc_tail = env("VP_DP_ENC_TAIL", "1") != "0"        # several ranks: the deep encoder convs in their own bucket
 
     # ---- buffers ----------------------------------------------------------------------------
     def _buf(self, name: str, *shape) -> torch.Tensor:
@@ -763,7 +775,7 @@ class FusedVAEStep:
 
     def _side_ctx(self):
         """(side stream, its events, fork event) when weight gradients run concurrently (bf16x3 plans, VP_SIDE_WGRAD != 0)."""
-        if not self._n_side_events or os.environ.get("VP_SIDE_WGRAD", "1") == "0":
+        if not self._n_side_events or not self._side_wgrad:
             return None
         if not hasattr(self, "_side"):
             self._side = _SideCtx(self._n_side_events)
@@ -860,7 +872,7 @@ class FusedVAEStep:
             "encoder conv parameters must form the head of the flat arena"
         return first
 
-    def step(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, overlap: bool = True):
+    def step(self, x: torch.Tensor, eps: torch.Tensor, timers: Optional[dict] = None, overlap: bool = True, comm_trace=None):
         """One full training step: fwd + loss + bwd, SUM all-reduce of the flat gradient arena, fused update.
 
         With several ranks the arena is reduced as four buckets of the same flat buffer, each handed to RCCL as
@@ -869,21 +881,44 @@ class FusedVAEStep:
         213 MB at config 3) after its weight gradient, the deep encoder blocks' conv slice (16.4 MB) while the shallow blocks
         still run backward, and the rest of the encoder's conv slice (< 1 MB) after backward; the
         optimiser kernel waits for all of them.  ``overlap=False`` issues one all-reduce of the whole arena.
+        ``comm_trace`` (parallel.CommTrace, instrumented steps of bench.py): every collective is issued through it, which
+        records its bytes, its device time and the time the main stream waits for collectives.
         (Updating each slice right after its all-reduce, on a second side stream underneath the rest of backward, was
         measured and is NOT done: the HBM-bound optimiser kernel slows the concurrent kernels by more than it hides,
         4.52 vs 4.46 ms/step on one GPU; ``optim.*.step_range`` remains available.)"""
+        tr = comm_trace
+
+        def reduce(name, t):         # SUM all-reduce of one bucket, issued now
+            if tr is not None:
+                return tr.issue(name, "all_reduce", t.numel() * 4, lambda: parallel.allreduce_flat_grads(t, self.group, async_op=True))
+            return parallel.allreduce_flat_grads(t, self.group, async_op=True)
+
+        def gather(name, out_all, local):
+            if tr is not None:
+                return tr.issue(name, "all_gather", out_all.numel() * 4,
+                                lambda: parallel.allgather_rows(out_all, local, self.group, async_op=True))
+            return parallel.allgather_rows(out_all, local, self.group, async_op=True)
+
+        def wait_all(works):
+            if tr is not None:
+                tr.wait()
+                return
+            for w in works:
+                if w is not None:
+                    w.wait()
+
         if parallel.dp_active(self.group) and overlap:
             g = self.opt.flat_grad
             cut = self._decoder_slice_start()
             dense = self._encoder_dense_start()
             works = []
-            factored = os.environ.get("VP_DP_FACTORED", "1") != "0"
+            factored = self._dp_factored
             # fourth cut: encoder.conv[i:] for the deepest blocks -- almost all of the encoder's conv parameters -- is reduced
             # while the remaining shallow blocks still run backward, so that only their < 1 MB is left for the exposed
             # all-reduce at the end of the step.  Its weight gradients are produced on the side stream and its BatchNorm
             # gradients on the main stream: the collective is issued from the side stream after it has joined the main one.
             tail_lo = dense
-            if getattr(self, "_bwd_b_enc_tail", None) is not None and os.environ.get("VP_DP_ENC_TAIL", "1") != "0":
+            if getattr(self, "_bwd_b_enc_tail", None) is not None and self._dp_enc_tail:
                 off = {id(p): o for p, o in zip(self.opt.arena.params, self.opt.arena.offsets)}
                 tail_lo = off[id(self.vae.encoder.conv[self._enc_tail_first].conv.weight)]
 
@@ -894,9 +929,9 @@ class FusedVAEStep:
                     side.flush()
                     side[0].wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side[0]):
-                        works.append(parallel.allreduce_flat_grads(g[tail_lo:dense], self.group, async_op=True))
+                        works.append(reduce("encoder.conv[deep]", g[tail_lo:dense]))
                 else:
-                    works.append(parallel.allreduce_flat_grads(g[tail_lo:dense], self.group, async_op=True))
+                    works.append(reduce("encoder.conv[deep]", g[tail_lo:dense]))
             if factored:
                 # fc.0's weight gradient (134 MB of the 213 MB at config 3) is dW = dh^T flat, a sum of B outer products
                 # per rank: exchange the two factors (W x 4.3 MB all-gather) and contract over all W*B rows locally
@@ -906,35 +941,32 @@ class FusedVAEStep:
                 if not hasattr(self, "_fc_all"):
                     self._fc_all = (torch.empty((W * B, 1024), device=self.dev), torch.empty((W * B, F0), device=self.dev))
                 dh_all, flat_all = self._fc_all
-                gather = []
+                gathers = []
                 fc_lo = self.opt.arena.offsets[[id(p) for p in self.opt.arena.params].index(id(fcw))]
                 fc_hi = fc_lo + (fcw.numel() + 63) // 64 * 64
 
                 def after_fwd():
-                    gather.append(parallel.allgather_rows(flat_all, flat.view(B, F0), self.group, async_op=True))
+                    gathers.append(gather("fc.0 factor: flat", flat_all, flat.view(B, F0)))
 
                 def fc_wgrad():
-                    w2 = parallel.allgather_rows(dh_all, dh.view(B, 1024), self.group, async_op=True)
-                    for w in gather + [w2]:
-                        w.wait()
+                    gathers.append(gather("fc.0 factor: dh", dh_all, dh.view(B, 1024)))
+                    wait_all(gathers)
                     ops.gemm(dh_all, 1, 1024, flat_all, 1, F0, 1024, F0, W * B, 2, out=self.opt.arena.grad_view(fcw).view(1024, F0))
 
                 def dense_bucket():
                     assert fc_lo == dense, "fc.0.weight must open the encoder's dense slice"
-                    works.append(parallel.allreduce_flat_grads(g[fc_hi:cut], self.group, async_op=True))
+                    works.append(reduce("encoder dense (without fc.0)", g[fc_hi:cut]))
 
                 out = self.forward_backward(
                     x, eps, timers, after_forward=after_fwd, on_fc_wgrad=fc_wgrad, on_dense_grads=dense_bucket, on_encoder_tail=enc_tail,
-                    on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)))
+                    on_decoder_grads=lambda: works.append(reduce("decoder", g[cut:])))
             else:
                 out = self.forward_backward(
                     x, eps, timers, on_encoder_tail=enc_tail,
-                    on_decoder_grads=lambda: works.append(parallel.allreduce_flat_grads(g[cut:], self.group, async_op=True)),
-                    on_dense_grads=lambda: works.append(parallel.allreduce_flat_grads(g[dense:cut], self.group, async_op=True)))
-            works.append(parallel.allreduce_flat_grads(g[:tail_lo], self.group, async_op=True))
-            for w in works:
-                if w is not None:
-                    w.wait()
+                    on_decoder_grads=lambda: works.append(reduce("decoder", g[cut:])),
+                    on_dense_grads=lambda: works.append(reduce("encoder dense", g[dense:cut])))
+            works.append(reduce("encoder.conv[shallow]" if tail_lo < dense else "encoder.conv", g[:tail_lo]))
+            wait_all(works)
         elif self.world == 1 and self._graph is None and self._outer_adam():      # (a captured graph replays the materialising plan)
             # one rank: encoder.fc.0's weight gradient (134 MB at config 3) is contracted from its two factors inside the Adam
             # kernel instead of being written by a GEMM and read back by the update; fc.0.weight.grad is NOT written by step()
@@ -944,7 +976,7 @@ class FusedVAEStep:
             # instead of behind it (VP_ADAM_OUTER_EARLY=0: at the end of the step; 1: fc.0 only; 2, the default: fc.0 and the arena
             # slice behind it.  3.640 / 3.609 / 3.572 ms in one process, tools/ab_env.py)
             early = None
-            if timers is None and os.environ.get("VP_ADAM_OUTER_EARLY", "2") != "0":
+            if timers is None and self._adam_outer_early:
                 def early():
                     side = self._side_ctx()
                     if side is None:
@@ -955,19 +987,21 @@ class FusedVAEStep:
                     with torch.cuda.stream(side.stream):
                         # (mode 2: also the arena slice behind fc.0 -- the rest of the encoder's dense layers and the whole decoder,
                         # whose weight gradients precede this launch on the side stream and whose other gradients the fork covers)
-                        self.opt.step_outer_early(with_tail=(os.environ.get("VP_ADAM_OUTER_EARLY", "2") == "2"
-                                                             and getattr(self, "_early_tail_ok", False)))
+                        self.opt.step_outer_early(with_tail=(self._adam_outer_early == 2 and getattr(self, "_early_tail_ok", False)))
             out = self.forward_backward(x, eps, timers, on_fc_wgrad=_noop, on_dense_grads=early)
             self.opt.step(outer=True)
             return out
         else:
             out = self.forward_backward(x, eps, timers)
-            parallel.allreduce_flat_grads(self.opt.flat_grad, self.group)
+            if parallel.dp_active(self.group):
+                wait_all([reduce("whole gradient arena", self.opt.flat_grad)])
+        if tr is not None:
+            tr.end_step()
         self.opt.step()
         return out
 
     def _outer_adam(self) -> bool:
-        if os.environ.get("VP_ADAM_OUTER", "1") == "0" or not hasattr(self.opt, "set_outer_grad"):
+        if not self._adam_outer or not hasattr(self.opt, "set_outer_grad"):
             return False
         # the factors are THIS engine's static buffers: bind them on every call in which the optimiser holds another engine's
         # (a second FusedVAEStep over the same optimiser -- another batch size, precision or a rebuilt plan -- would otherwise
@@ -997,8 +1031,12 @@ class FusedVAEStep:
                 self._launch_all()
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._launch_all()
+        ops.CAPTURE_OK[0] = True          # (ops._stream() refuses captures it does not know: the autograd front end's)
+        try:
+            with torch.cuda.graph(g):
+                self._launch_all()
+        finally:
+            ops.CAPTURE_OK[0] = False
         self._graph = g
         for m, rm, rv in saved:
             m.running_mean.copy_(rm)

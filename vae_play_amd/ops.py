@@ -32,11 +32,27 @@ def _p(t: Optional[torch.Tensor]):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+CAPTURE_OK = [False]     # set by the fused plans (engine.FusedVAEStep.capture) around their own hipGraph capture
+
+
 def _stream():
     """The current HIP stream of the current device as a raw pointer.  torch.cuda.current_stream() builds a Stream object per call
-    (13 % of the host time of a launch-bound autograd step); torch's raw-stream accessor is one C call."""
+    (13 % of the host time of a launch-bound autograd step); torch's raw-stream accessor is one C call.
+
+    hipGraph capture of the AUTOGRAD front end is refused here, before anything is launched into the capture: autograd's
+    AccumulateGrad nodes live on the stream their parameters were first used on (normally the default stream), the engine
+    synchronises that stream with the capturing one -- illegal inside a capture -- and every launch after that returns
+    "capture invalidated" on an autograd worker thread, which ends the process (round 2: gpurun_out/be_graph.err, a core dump
+    right after torch's AccumulateGrad-stream warning).  The pre-planned steps (engine.FusedVAEStep / engine_gan.FusedVAEGANStep)
+    are the graph-capturable front ends.  The check costs nothing on the default stream (raw handle 0), where no capture can run."""
     if _raw_stream is not None:
-        return c_void_p(_raw_stream(torch.cuda.current_device()))
+        h = _raw_stream(torch.cuda.current_device())
+        if h and not CAPTURE_OK[0] and torch.cuda.is_current_stream_capturing():
+            raise _lib.VaePlayHipError(
+                "hipGraph capture of the autograd front end is not supported (autograd's AccumulateGrad nodes synchronise with "
+                "the stream their parameters were first used on, which invalidates the capture and aborts the process); "
+                "capture engine.FusedVAEStep / engine_gan.FusedVAEGANStep instead, or run this step eagerly")
+        return c_void_p(h)
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -66,6 +66,68 @@ def allgather_rows(out_all: torch.Tensor, local: torch.Tensor, group=None, async
     return dist.all_gather(chunks, local, group=group, async_op=async_op)
 
 
+class CommTrace:
+    """Evidence hooks for the first real multi-GPU run (bench.py ``comm``): per collective of a step its name, kind, bytes and
+    the device time from "its inputs are final on the producing stream" to "its result is ready" -- an event pair on a
+    communicator-side stream that waits for the producer, issues the collective and waits for it (collectives are serialised
+    on the backend's own stream, so the pair includes queueing behind earlier buckets: that IS what the step sees) -- and
+    ``exposed``: the time the main stream spends blocked in waits for collectives.  Used on instrumented steps only; the
+    un-traced step hands its buckets to the backend directly."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+        self.records = []          # (name, kind, bytes, e0, e1)
+        self.waits = []            # (e0, e1) on the waiting stream
+        self.steps = 0
+
+    def issue(self, name: str, kind: str, nbytes: int, fn):
+        """``fn()`` issues the collective (async) on the current stream context; returns an object with ``wait()``."""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.stream):
+            e0.record()
+            w = fn()
+            if w is not None:
+                w.wait()
+            e1.record()
+        self.records.append((name, kind, int(nbytes), e0, e1))
+        return self
+
+    def wait(self):
+        """the current stream waits for everything issued so far; the stall is recorded as exposed time"""
+        cur = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        cur.wait_stream(self.stream)
+        e1.record(cur)
+        self.waits.append((e0, e1))
+
+    def end_step(self):
+        self.steps += 1
+
+    def summary(self) -> dict:
+        """after a synchronize: per-bucket averages over the traced steps"""
+        torch.cuda.synchronize()
+        n = max(self.steps, 1)
+        by = {}
+        for name, kind, nbytes, e0, e1 in self.records:
+            d = by.setdefault(name, {"name": name, "kind": kind, "bytes": nbytes, "ms": 0.0, "calls": 0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["calls"] += 1
+        buckets = []
+        for d in by.values():
+            d["ms"] = round(d["ms"] / d["calls"], 4)
+            d["calls_per_step"] = d.pop("calls") / n
+            buckets.append(d)
+        exposed = sum(e0.elapsed_time(e1) for e0, e1 in self.waits) / n
+        kinds = {}
+        for b in buckets:
+            kinds[b["kind"]] = kinds.get(b["kind"], 0) + b["calls_per_step"]
+        return {"buckets": buckets, "exposed_ms_per_step": round(exposed, 4),
+                "collectives_per_step": {k: round(v, 3) for k, v in kinds.items()},
+                "bytes_per_step": int(sum(b["bytes"] * b["calls_per_step"] for b in buckets)), "traced_steps": self.steps}
+
+
 def broadcast_flat_params(flat_param: torch.Tensor, src: int = 0, group=None) -> None:
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_param, src=src, group=group)
