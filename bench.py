@@ -37,16 +37,17 @@ STEP_GFLOP = {32: 0.6141, 64: 4.0301, 128: 22.2088, 256: 112.0225}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32", "vp_conv5_gather_stats_bf16x3", "vp_conv5_scatter_stats_bf16x3",
-              "vp_conv5_gather_bf16x3", "vp_conv5_scatter_bf16x3", "vp_conv5_wgrad_bf16x3", "vp_conv5_gather_bnbwd_bf16x3",
-              "vp_conv5_scatter_bnbwd_bf16x3",
+              "vp_conv5_gather_bf16x3", "vp_conv5_scatter_bf16x3", "vp_conv5_wgrad_bf16x3",
               "vp_conv_gather_bf16x3", "vp_conv_wgrad_bf16x3",
               "vp_conv5_smallin_dgrad_bf16x3", "vp_conv5_smallout_bf16x3", "vp_conv5_smallout_wgrad_bf16x3", "vp_conv5_gather_f16", "vp_conv5_scatter_f16", "vp_conv5_wgrad_f16x2", "vp_conv5_gather_stats_f16",
-              "vp_conv5_scatter_stats_f16", "vp_conv_gather_f16", "vp_conv_wgrad_f16x2"}
+              "vp_conv5_scatter_stats_f16", "vp_conv_gather_f16", "vp_conv_wgrad_f16x2",
+              "vp_conv5_wgrad_bf16x3_cus", "vp_conv5_wgrad_f16x2_cus", "vp_conv5_wgrad_f32_cus"}
 
 
 def mfma_products(name, tag):
     """MFMAs issued per algorithmic product by the launch `name` (tag = its layer): 3 on bf16 pairs, 3 (forward layers) or 2
     (backward layers) on fp16 pairs, 1 on the exact-fp32 kernels."""
+    name = name.replace("_cus", "")      # (the weight gradients' entry points with a CU budget: same kernels)
     if name.endswith("bf16x3"):
         return 3
     if name.endswith("_f16x2"):
@@ -234,7 +235,7 @@ def measure(fused, x, eps, steps, untimed, world, graph, overlap=True, tags_out=
         measured = "instrumented-pass-after-timed-region"
     fam = {}
     for name, tag, flops, e0, e1 in timers["events"]:
-        d = fam.setdefault(name.replace("_stats_", "_").replace("_bnbwd_", "_"), [0.0, 0.0, 0, 0.0])
+        d = fam.setdefault(name.replace("_stats_", "_").replace("_cus", ""), [0.0, 0.0, 0, 0.0])
         d[0] += flops
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
@@ -261,9 +262,10 @@ def roofline_of(m, steps, B, S, C, z):
     is16 = dom.endswith("bf16x3") or dom.endswith("f16x2") or dom.endswith("_f16")
     per_product = fam[dom][3] / fam[dom][0]      # MFMAs per product, averaged over the family's launches (fp16: 3 forward, 2 backward)
     peak = PEAK_BF16_MFMA_TFLOPS if is16 else PEAK_FP32_MFMA_TFLOPS       # fp16 and bf16 MFMAs have the same dense peak
-    kdesc = ("igemm16_kernel, 3 x v_mfma_f32_32x32x16_bf16 per product" if dom.endswith("bf16x3")
-             else "igemm16_kernel, 2 (backward) or 3 (forward) x v_mfma_f32_32x32x16_f16 per product" if is16
-             else "igemm_kernel, v_mfma_f32_32x32x2_f32")
+    kern = "wgrad5_kernel (one kernel row of 5 taps per workgroup) + slab reduction" if "wgrad" in dom else "igemm16_kernel"
+    kdesc = (f"{kern}, 3 x v_mfma_f32_32x32x16_bf16 per product" if dom.endswith("bf16x3")
+             else f"{kern}, 2 (backward) or 3 (forward) x v_mfma_f32_32x32x16_f16 per product" if is16
+             else ("wgrad5f_kernel (rows of taps) + slab reduction" if "wgrad" in dom else "igemm16_kernel in fp32 mode") + ", v_mfma_f32_32x32x2_f32")
     # the committed PMC passes were taken on the default workload only
     traffic, traffic_src = measured_traffic(dom) if (S, C, z, B) == (128, 3, 128, 32) else (None, None)
     return {"bound": "mfma", "kernel": f"{dom} ({kdesc})",

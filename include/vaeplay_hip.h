@@ -63,6 +63,9 @@ size_t vp_conv5_wgrad_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmal
 int vp_conv5_wgrad_f32(const float* big, const float* small, float* dw_ref,
                        int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
                        void* ws, size_t ws_bytes, vp_stream stream);
+/* As vp_conv5_wgrad_f32 with a bound on the CUs the launch occupies (see vp_conv5_wgrad_bf16x3_cus; max_cus <= 0: the whole chip). */
+int vp_conv5_wgrad_f32_cus(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Cbig, int Csmall,
+                           int stride, int max_cus, void* ws, size_t ws_bytes, vp_stream stream);
 
 /* ---- k x k generalisation (ks = 1, 3 or 5, padding (ks-1)/2, stride 1 or 2) -------------------------------------
  * The conv/norm/act vocabulary of models/blocks.py:5-34 (nn.Conv2d(k, stride, padding=(k-1)//2)); same three families.
@@ -150,27 +153,18 @@ int vp_conv5_smallin_dgrad_bf16x3(const float* small, const float* w_ref, float*
  * fp32 NHWC operands, reference weight layout, act none | relu; the same rows-in-K kernel as vp_conv5_smallin_dgrad_bf16x3. */
 int vp_conv5_smallin_fwd_bf16x3(const float* small, const float* w_ref, const float* bias, float* big_out, int B, int H, int W, int Csmall,
                                 int Cbig, int act, vp_stream stream);
-/* Input-gradient convolution + the reduction pass of the BatchNorm backward it feeds (autograd of nn.BatchNorm2d + F.relu,
- * models/networks.py:28-29,44-45): the launch's output small_out / big_out is dy of a BatchNorm(+ReLU) layer whose convolution
- * output is bn_x (same layout); the epilogue emits per-workgroup {sum g, sum g*xhat}, g = dy * act'(gamma*xhat + beta), and one
- * finaliser writes sums[0..C) = sum g, sums[C..2C) = sum g*xhat and the affine gradients (dbeta = sum g, dgamma = sum g*xhat;
- * either may be NULL).  vp_bn_act_bwd_apply_split_f32 then produces dx from them: together they replace vp_bn_act_bwd_split_f32
- * without its separate read of dy and x for the sums.  Shapes: as vp_conv5_*_stats_bf16x3 (same workspace query). */
-int vp_conv5_gather_bnbwd_bf16x3(const void* big_split, const void* w_p0_split, float* small_out,
-                                 int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
-                                 const float* bn_x, const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
-                                 int act, float* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vp_stream stream);
-int vp_conv5_scatter_bnbwd_bf16x3(const void* small_split, const void* w_p1_split, float* big_out,
-                                  int B, int Hs, int Ws, int Csmall, int Cbig, int stride,
-                                  const float* bn_x, const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
-                                  int act, float* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, vp_stream stream);
-int vp_bn_act_bwd_apply_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                                  const float* beta, const float* sums, float* dx, void* dx_split, int R, int C, int act, float slope,
-                                  int batch_stats, vp_stream stream);
 size_t vp_conv5_wgrad_bf16x3_workspace_bytes(int B, int Hs, int Ws, int Cbig, int Csmall, int stride);
 int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref,
                           int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
                           void* ws, size_t ws_bytes, vp_stream stream);
+/* The same with a bound on the CUs the launch occupies.  The row-of-taps kernel (csrc/wgrad5.h: one kernel row of 5 taps per
+ * workgroup, replaces cuDNN's weight gradient behind models/networks.py:14,38) owns a whole CU per work item; a caller that runs the
+ * weight gradient BESIDE other kernels -- the fused step's side stream -- leaves the rest of the chip to them (160 of 256 CUs is the
+ * measured optimum there).  max_cus <= 0: the whole chip (= vp_conv5_wgrad_bf16x3).  Same workspace query, same result up to the
+ * summation order of the pixel ranges. */
+int vp_conv5_wgrad_bf16x3_cus(const void* big_split, const void* small_split, float* dw_ref,
+                              int B, int Hs, int Ws, int Cbig, int Csmall, int stride, int max_cus,
+                              void* ws, size_t ws_bytes, vp_stream stream);
 /* Weight gradient of a 3x3 / stride 1 / padding 1 nn.Conv2d with a handful of channels on both sides (Cin <= 40, Cout <= 8: the mask /
  * edge heads of models/networks_BE.py:39-66 via models/blocks.py:9-17), exact fp32 on the vector ALUs: x (B, H, W, Cin) and dy (B, H, W,
  * Cout) NHWC, dw_ref (Cout, Cin, 3, 3); bit-reproducible.  vp_conv3_small_wgrad_workspace_bytes() == 0: shape not taken. */
@@ -306,6 +300,11 @@ int vp_global_avgpool_bwd_f32(const float* dy, float* dx_nhwc, int B, int HW, in
 /* nn.Softmax(dim=-1) over R rows of n; bwd: dx = y * (dy - sum_j dy_j y_j) */
 int vp_softmax_rows_fwd_f32(const float* x, float* y, int R, int n, vp_stream stream);
 int vp_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, int R, int n, vp_stream stream);
+/* F.cross_entropy(logits, labels) with torch's defaults (mean over the R rows; labels int64 class indices): train_BE_GAN.py:135,159
+ * (d_type_loss / g_type_loss), train_BE_font.py:109.  loss[0] = mean_r (logsumexp(x_r) - x_r[label_r]); prob (R x n) = softmax rows,
+ * kept for the backward pass: dlogits = g[0] / R * (prob - onehot(labels)).  Bit-reproducible (fixed-order sum in fp64). */
+int vp_cross_entropy_fwd_f32(const float* logits, const long long* labels, float* loss, float* prob, int R, int n, vp_stream stream);
+int vp_cross_entropy_bwd_f32(const float* prob, const long long* labels, const float* gptr, float* dlogits, int R, int n, vp_stream stream);
 /* F.l1_loss(a, b) (mean): out[0]; ws >= 2 * vp_reduce_workspace_bytes(n).  bwd: da = g * sign(a-b) / n, db = -da */
 int vp_l1_mean_f32(const float* a, const float* b, size_t n, float* out, void* ws, size_t ws_bytes, vp_stream stream);
 int vp_l1_mean_bwd_f32(const float* a, const float* b, const float* gptr, float* da, float* db, size_t n, vp_stream stream);
@@ -389,6 +388,8 @@ int vp_conv_scatter_f16(const void* small_split, const void* w_p1_split, float* 
                         int Csmall, int Cbig, int ks, int stride, int products, float out_scale, vp_stream stream);
 int vp_conv5_wgrad_f16x2(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,
                          int Csmall, int stride, float out_scale, void* ws, size_t ws_bytes, vp_stream stream);
+int vp_conv5_wgrad_f16x2_cus(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,
+                             int Csmall, int stride, float out_scale, int max_cus, void* ws, size_t ws_bytes, vp_stream stream);
 int vp_conv_wgrad_f16x2(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
                         int Csmall, int ks, int stride, float out_scale, void* ws, size_t ws_bytes, vp_stream stream);
 /* forward layers with the BatchNorm statistics in the epilogue (as vp_conv5_*_stats_bf16x3; own workspace query because the

@@ -16,6 +16,7 @@ sys.dont_write_bytecode = True
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -199,6 +200,137 @@ def gan_disc_fixture(blocks, in_size, B):
     return fx
 
 
+def ref_gan_discriminator(blocks, in_size, num_classes=5):
+    """models/networks_BE_GAN.py:74-139 from the reference's own blocks (as in gan_disc_fixture)."""
+    import math
+
+    def mapper(cin, max_channel):
+        m = nn.Module()
+        m.convs = nn.Sequential(blocks.Conv2d(cin, 16, 3, 2, bn=None, activate="lrelu"), blocks.Conv2d(16, 32, 3, 2, bn=None, activate="lrelu"))
+        c, nxt = 32, min(64, max_channel)
+        m.feat_modules = nn.ModuleList()
+        for _ in range(int(math.log2(in_size // 16)) - 2):
+            m.feat_modules.append(nn.Sequential(blocks.Conv2d(c, nxt, 3, 2, bn="batch", activate="lrelu"),
+                                                blocks.Conv2d(nxt, nxt, 3, 1, bn="batch", activate="lrelu")))
+            c, nxt = nxt, min(nxt * 2, max_channel)
+        m.pooler = nn.Sequential(blocks.Conv2d(c, max_channel, 1, 1, bn=None, activate=None), nn.AdaptiveAvgPool2d((1, 1)))
+
+        def run(x, msk):
+            x = m.convs(torch.cat([x, msk], dim=1))
+            feats = []
+            for idx, mod in enumerate(m.feat_modules):
+                x = mod(x)
+                feats.append(x.reshape(x.size(0), -1) * (idx // 2 + 1))
+            x = m.pooler(x)
+            return x.reshape(x.size(0), -1), torch.cat(feats, dim=1)
+        m.run = run
+        return m
+
+    d = nn.Module()
+    d.content_disc, d.boundary_disc = mapper(2, 64), mapper(2, 64)
+    d.predictor = nn.Sequential(blocks.Linear(128, 128, bias=True, activate="lrelu"), blocks.Linear(128, 64, bias=True, activate="lrelu"),
+                                blocks.Linear(64, num_classes, bias=False, activate=None))
+
+    def run(x, m1, m2):
+        x0 = x[:, 0, :, :].reshape(x.size(0), 1, x.size(2), x.size(3))
+        a, fa = d.content_disc.run(x0, m1)
+        b, fb = d.boundary_disc.run(x0, m2)
+        return d.predictor(torch.cat([a, b], dim=1)), torch.cat([fa, fb], dim=1)
+    d.run = run
+    return d
+
+
+def gan_train_fixture(blocks, in_size, B, feat_ch, iters):
+    """train_BE_GAN.py:131-165 with the reference's blocks modules below the backbone, torch's own cross-entropy /
+    BCE-with-logits / Adam, next to oracle/ref_be.gan_train_iteration: bit equality of all seven losses and of every
+    parameter after every iteration."""
+    gen = nn.Module()
+    layers, c = [], feat_ch
+    for _ in range(int(np.log2(feat_ch // 64))):
+        layers.append(blocks.Conv2d(c, c // 2, 1, stride=1, bn="batch"))
+        layers.append(blocks.Conv2d(c // 2, c // 2, 3, stride=1, bn="batch"))
+        c //= 2
+    gen.aux_convs = nn.Sequential(*layers)
+    gen.mask_net, gen.edge_net = ref_masknet(blocks, 64), ref_masknet(blocks, 64)
+    gen.load_state_dict(BE.seeded_weights(gen.state_dict(), 555))
+    disc = ref_gan_discriminator(blocks, in_size)
+    disc.load_state_dict(BE.seeded_weights(disc.state_dict(), 666))
+    gen.train(); disc.train()
+    g = torch.Generator().manual_seed(41)
+    H = in_size // 4
+    feature = torch.randn(B, feat_ch, H, H, generator=g)
+    imgs = torch.rand(B, 3, in_size, in_size, generator=g)
+    bimgs = (torch.rand(B, 1, in_size, in_size, generator=g) > 0.5).float()
+    eimgs = (torch.rand(B, 1, in_size, in_size, generator=g) > 0.8).float()
+    labels = torch.randint(0, 5, (B,), generator=g)
+    lr = 1e-4
+    g_ropt = torch.optim.Adam(gen.parameters(), lr=lr, betas=(0.5, 0.999))          # train_BE_GAN.py:236
+    d_ropt = torch.optim.Adam(disc.parameters(), lr=lr * 0.1, betas=(0.5, 0.999))   # :237
+    pg = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    pd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
+    O.require_grad(pg); O.require_grad(pd)
+    g_oopt, d_oopt = BE.gan_make_optimizers(pg, pd, lr)
+
+    def gen_run(f):
+        h = gen.aux_convs(f)
+        return {"masks": gen.mask_net.run(h), "edges": gen.edge_net.run(h)}
+    fx = {"meta_S": in_size, "meta_B": B, "meta_C": feat_ch, "meta_iters": iters, "gen_seed": np.array(555), "disc_seed": np.array(666),
+          "feature": np_(feature), "imgs": np_(imgs), "bimgs": np_(bimgs), "eimgs": np_(eimgs), "labels": labels.numpy().copy()}
+    names = ("d_adv_loss", "d_type_loss", "loss_edge", "loss_mask", "g_adv_loss", "g_type_loss", "loss_cnt")
+    for it in range(1, iters + 1):
+        # ---- the reference's loop body, verbatim in structure (train_BE_GAN.py:131-165) ----
+        with torch.no_grad():
+            preds = gen_run(feature)
+            pred_masks = preds["masks"].sigmoid()
+            pred_edges = preds["edges"].sigmoid()
+        d_real_type, d_real_feats = disc.run(imgs, bimgs, eimgs)
+        d_fake_type, d_fake_feats = disc.run(imgs, pred_masks, pred_edges)
+        d_adv_loss = 1 - torch.mean(torch.abs(d_fake_feats - d_real_feats))
+        d_type_loss = F.cross_entropy(d_real_type, labels)
+        d_losses = d_adv_loss + d_type_loss
+        d_ropt.zero_grad()
+        d_losses.backward()
+        d_ropt.step()
+        preds = gen_run(feature)
+        pred_masks, pred_edges = preds["masks"], preds["edges"]
+        with torch.no_grad():
+            _, g_real_feats = disc.run(imgs, bimgs, eimgs)
+        g_pred_type, g_pred_feats = disc.run(imgs, pred_masks.sigmoid(), pred_edges.sigmoid())
+        loss_mask = 0.5 * F.binary_cross_entropy_with_logits(pred_masks, bimgs) + BE.dice_loss(pred_masks.sigmoid(), bimgs)
+        loss_egde = 0.5 * F.binary_cross_entropy_with_logits(pred_edges, eimgs) + BE.dice_loss(pred_edges.sigmoid(), eimgs)
+        g_adv_loss = torch.mean(torch.abs(g_pred_feats - g_real_feats))
+        g_type_loss = F.cross_entropy(g_pred_type, labels)
+        loss_cnt = BE.edge_loss(pred_masks.sigmoid(), bimgs) + BE.edge_loss(pred_edges.sigmoid(), eimgs)
+        losses = loss_mask * 2 + loss_egde * 2 + g_adv_loss + g_type_loss + loss_cnt * 0.5
+        g_ropt.zero_grad()
+        losses.backward()
+        g_ropt.step()
+        ref = {"d_adv_loss": d_adv_loss, "d_type_loss": d_type_loss, "loss_edge": loss_egde, "loss_mask": loss_mask,
+               "g_adv_loss": g_adv_loss, "g_type_loss": g_type_loss, "loss_cnt": loss_cnt}
+        # ---- the oracle ----
+        o = BE.gan_train_iteration(pg, pd, g_oopt, d_oopt, feature, imgs, bimgs, eimgs, labels, in_size, feat_ch)
+        for k in names:
+            bit_equal(o[k], ref[k].detach(), f"{k} iteration {it}")
+            fx[f"{k}{it}"] = np_(ref[k].detach().double().reshape(1))
+        bit_equal(o["masks"], pred_masks.detach(), f"masks iteration {it}")
+        for net, pp, tag in ((gen, pg, "g"), (disc, pd, "d")):
+            rsd = net.state_dict()
+            for n in pp:
+                bit_equal(pp[n].detach(), rsd[n].detach(), f"{tag} param {n} iteration {it}")
+        if it == 1:
+            fx["masks1"], fx["edges1"] = np_(pred_masks.detach()), np_(pred_edges.detach())
+        for tag, pp in (("g", pg), ("d", pd)):
+            for n in O.trainable_names(pp):
+                t_ = pp[n].detach()
+                fx[f"param{it}/{tag}/{n}"] = np_(torch.stack([t_.double().sum(), t_.double().pow(2).sum()]))
+                fx[f"psample{it}/{tag}/{n}"] = np_(t_.flatten()[:: max(1, t_.numel() // 64)][:64])
+    for tag, pp in (("g", pg), ("d", pd)):
+        for n in pp:
+            if "running" in n:
+                fx[f"bn/{tag}/{n}"] = np_(pp[n])
+    return fx
+
+
 def main():
     _, blocks = import_reference()
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -211,6 +343,7 @@ def main():
     save("be_heads_c32_b2_h16", heads_fixture(blocks, 32, 2, 16, 2))
     save("be_aux_c128_to32", aux_fixture(blocks, 128, 32, 2, 12))
     save("be_gan_disc128_b2", gan_disc_fixture(blocks, 128, 2))
+    save("be_gan_train128_b2", gan_train_fixture(blocks, 128, 2, 128, 2))
     print("oracle == reference blocks composition (bit-exact) on every BE fixture")
 
 

@@ -156,3 +156,58 @@ def edge_loss(mask_probs: torch.Tensor, mask_targets: torch.Tensor) -> torch.Ten
     k[1, 1] = 8.0
     k = (k / 8).reshape(1, 1, 3, 3)
     return dice_loss(F.conv2d(mask_probs, k, padding=1).abs(), F.conv2d(mask_targets, k, padding=1).abs())
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# train_BE_GAN.py:131-165 -- the two-phase loop body (discriminator step, generator step), below the backbone.
+# Pinning: the NETWORKS are the blocks compositions above (pinned through the reference's own blocks by
+# oracle/gen_golden_be.py: be_gan_train128_b2 runs this function next to the same loop body written with the reference's
+# blocks modules, torch's own F.cross_entropy / F.binary_cross_entropy_with_logits and torch.optim.Adam, and asserts bit
+# equality of the seven losses and of every parameter after each iteration).  compute_dice_loss / edge_loss are the
+# restatements above on BOTH sides: parity unpinned for those two functions (tools/ops.py needs cv2).
+# --------------------------------------------------------------------------------------------------------------------
+def gan_generator_forward(p: Params, feature: torch.Tensor, feat_channels: int, training: bool = True):
+    """models/networks_BE_GAN.py:60-72 below the backbone: aux_convs down to 64 channels, then the mask and the edge head."""
+    h = aux_convs_forward(p, feature, feat_channels, 64, training, "aux_convs.")
+    return {"masks": masknet_forward(p, h, training, "mask_net."), "edges": masknet_forward(p, h, training, "edge_net.")}
+
+
+def gan_make_optimizers(pg: Params, pd: Params, lr: float = 1e-4):
+    """train_BE_GAN.py:236-237: Adam(G, lr, betas (0.5, 0.999)), Adam(D, 0.1 lr, betas (0.5, 0.999))."""
+    return (torch.optim.Adam([pg[n] for n in O.trainable_names(pg)], lr=lr, betas=(0.5, 0.999)),
+            torch.optim.Adam([pd[n] for n in O.trainable_names(pd)], lr=lr * 0.1, betas=(0.5, 0.999)))
+
+
+def gan_train_iteration(pg: Params, pd: Params, g_opt, d_opt, feature, imgs, bimgs, eimgs, labels, in_size: int, feat_channels: int):
+    """One iteration of train_BE_GAN.py:131-165 (``feature`` = the backbone's stride-4 map of ``imgs``: the backbone is out of
+    scope).  Returns the seven scalars the reference logs (:167-175)."""
+    # D (:131-144)
+    with torch.no_grad():
+        preds = gan_generator_forward(pg, feature, feat_channels, True)
+        pred_masks, pred_edges = preds["masks"].sigmoid(), preds["edges"].sigmoid()
+    d_real_type, d_real_feats = gan_discriminator_forward(pd, imgs, bimgs, eimgs, in_size, True)
+    d_fake_type, d_fake_feats = gan_discriminator_forward(pd, imgs, pred_masks, pred_edges, in_size, True)
+    d_adv_loss = 1 - torch.mean(torch.abs(d_fake_feats - d_real_feats))
+    d_type_loss = F.cross_entropy(d_real_type, labels)
+    d_losses = d_adv_loss + d_type_loss
+    d_opt.zero_grad()
+    d_losses.backward()
+    d_opt.step()
+    # G (:147-165)
+    preds = gan_generator_forward(pg, feature, feat_channels, True)
+    pred_masks, pred_edges = preds["masks"], preds["edges"]
+    with torch.no_grad():
+        _, g_real_feats = gan_discriminator_forward(pd, imgs, bimgs, eimgs, in_size, True)
+    g_pred_type, g_pred_feats = gan_discriminator_forward(pd, imgs, pred_masks.sigmoid(), pred_edges.sigmoid(), in_size, True)
+    loss_mask = be_loss(pred_masks, bimgs)
+    loss_edge = be_loss(pred_edges, eimgs)
+    g_adv_loss = torch.mean(torch.abs(g_pred_feats - g_real_feats))
+    g_type_loss = F.cross_entropy(g_pred_type, labels)
+    loss_cnt = edge_loss(pred_masks.sigmoid(), bimgs) + edge_loss(pred_edges.sigmoid(), eimgs)
+    losses = loss_mask * 2 + loss_edge * 2 + g_adv_loss + g_type_loss + loss_cnt * 0.5
+    g_opt.zero_grad()
+    losses.backward()
+    g_opt.step()
+    return {"d_adv_loss": d_adv_loss.detach(), "d_type_loss": d_type_loss.detach(), "loss_edge": loss_edge.detach(),
+            "loss_mask": loss_mask.detach(), "g_adv_loss": g_adv_loss.detach(), "g_type_loss": g_type_loss.detach(),
+            "loss_cnt": loss_cnt.detach(), "masks": pred_masks.detach(), "edges": pred_edges.detach()}

@@ -57,7 +57,7 @@ def test_fused_step_against_reference_golden(name, precision):
                 # contraction noise is amplified along the backward chain by small-batch BatchNorm,
                 # so each gradient tensor's norm is held to 5e-3 (measured worst: 2.6e-3 at batch 4).
                 # The batch-4 fixtures amplify even fp32 rounding-ORDER noise the same way (BatchNorm1d over 4 samples):
-                # two dense kernels that are both 2e-7 from the fp64 product (tools/skinny_accuracy.py) moved
+                # two dense kernels that are both 2e-7 from the fp64 product (round-1 measurement, profiles/r01_c_notes.md) moved
                 # encoder.l_var.bias from 4.8e-4 to 1.7e-3, so exact-fp32 mode keeps the 1e-3 bar at batch 32 only.
                 # f16x2 (forward on three fp16 products, backward on two: ~2e-4 of contraction noise per backward layer) is held
                 # to bf16x3's budgets (measured worst gradient norm 9.4e-4); its per-tensor accuracy claim is
@@ -162,6 +162,10 @@ def test_concurrent_schedule_is_bit_identical_to_the_serial_one(monkeypatch):
     from vae_play_amd import optim
     from vae_play_amd.engine import FusedVAEStep
     states = []
+    # (the weight gradients take the side stream's CU budget on BOTH streams here: their pixel ranges -- the summation order of the
+    # slabs -- follow the budget, and the production step gives them the whole chip when they run alone on the main stream)
+    monkeypatch.setenv("VP_WGRAD_MAIN_CUS", "160")
+    monkeypatch.setenv("VP_WGRAD_SIDE_CUS", "160")
     for mode in ("1", "0"):
         monkeypatch.setenv("VP_SIDE_WGRAD", mode)
         torch.manual_seed(3)

@@ -198,3 +198,137 @@ def test_vaegan_per_loss_gradients_against_fp64_oracle():
             record(f"vaegan/{k}/hip_vs_fp64/{n}", e_hip)
             record(f"vaegan/{k}/oracle32_vs_fp64/{n}", e_o32)
             assert e_hip <= max(2 * e_o32, 1e-5), f"{k} d/d {n}: HIP {e_hip:.2e}, fp32 oracle {e_o32:.2e} (both vs fp64)"
+
+
+# ---- fused VAE-GAN plan (split-bf16) against the fp64 oracle, ReLU masks matched ---------------------------
+class _MaskedRelu:
+    """``torch.nn.functional.relu`` replaced, for the duration of one oracle evaluation, by a multiplication with a 0/1 mask:
+    masks=None records the masks the pre-activations give (= F.relu), otherwise the given masks are applied in call order.
+    The oracle modules (oracle/ref_cpu.py, oracle/ref_vaegan.py) call F.relu for every ReLU of the step, so the restatement itself
+    is what gets evaluated -- no second copy of the model here."""
+
+    def __init__(self, dt, masks=None):
+        self.dt, self.masks, self.used = dt, masks, []
+
+    def __enter__(self):
+        self._orig = F.relu
+
+        def relu(t, inplace=False):
+            m = (t > 0).to(self.dt) if self.masks is None else self.masks[len(self.used)].to(self.dt)
+            self.used.append(m.detach())
+            return t * m
+        F.relu = relu
+        return self
+
+    def __exit__(self, *exc):
+        F.relu = self._orig
+        return False
+
+
+def _vaegan_total(p0, batch, S, dt, c_disc, c_mse, masks=None):
+    """Gradient of the summed losses of train.py:61-73 with the coefficients the one-pass plan uses (c_disc: 1 from
+    loss_discriminator minus (1 - lambda) from loss_decoder, as fp32 forms it; c_mse = 1 + lambda), per parameter tensor."""
+    from oracle import ref_cpu as O
+    from oracle import ref_vaegan as G
+    x, targets, eps, z_p = (t.to(dt) for t in batch)
+    p = {k: (v.to(dt).clone() if v.dtype.is_floating_point else v.clone()) for k, v in p0.items()}
+    O.require_grad(p)
+    with _MaskedRelu(dt, masks) as mr:
+        out, losses = G.train_losses(p, x, targets, eps, z_p, S)
+    total = (losses["loss_recon"] + torch.sum(out["kl"]) + c_mse * torch.sum(out["mse"]) + c_disc * losses["loss_discriminator"]
+             + losses["loss_aux"])
+    names = O.trainable_names(p)
+    gs = torch.autograd.grad(total, [p[n] for n in names], allow_unused=True)
+    return {n: g.detach() for n, g in zip(names, gs) if g is not None}, {k: v.detach() for k, v in out.items()}, mr.used
+
+
+def _gan_masks(fused, B, S, L):
+    """ReLU masks of the fused VAE-GAN forward pass in the oracle's call order: encoder blocks, encoder fc, decoder(z) fc + blocks,
+    decoder(z_p) fc + blocks, then the discriminator's stem + blocks twice ("REC" and "GAN" see the same activations) + its fc."""
+    from vae_play_amd import ops
+    bufs = fused._bufs
+
+    def act(name, n):
+        if name + "s" in bufs and name not in bufs:
+            return ops.unsplit(bufs[name + "s"])[:n]
+        return bufs[name].flatten()[:n]
+
+    def nhwc(name, n, H, C):
+        return (act(name, n * H * H * C).view(n, H, H, C).permute(0, 3, 1, 2) > 0).cpu()
+    net = fused.net
+    out = []
+    for i, blk in enumerate(net.encoder.conv):
+        out.append(nhwc(f"enc{i}.a", B, S >> (i + 1), blk.conv.weight.shape[0]))
+    out.append((bufs["enc.hb"].view(B, -1) > 0).cpu())
+    for tag in ("dec", "decp"):
+        out.append((bufs[f"{tag}.db"].view(B, -1) > 0).cpu())
+        for i in range(L):
+            out.append(nhwc(f"{tag}{i}.u", B, 16 << i, net.decoder.conv[i].conv.weight.shape[1]))
+    n3 = 3 * B
+    disc = [nhwc("disc0.y", n3, S, net.discriminator.conv[0][0].weight.shape[0])]
+    for i in range(1, L + 1):
+        disc.append(nhwc(f"disc{i}.a", n3, S >> i, net.discriminator.conv[i].conv.weight.shape[0]))
+    out += disc + disc
+    out.append((bufs["disc.hb"].view(n3, -1) > 0).cpu())
+    return out
+
+
+GAN_GRAD_FLOOR = 3e-4      # split-bf16 given the same masks (the plain VAE's floor is 2e-4; the VAE-GAN chains three networks)
+
+
+@pytest.mark.parametrize("S,z,B", [(64, 32, 4), (128, 128, 16)])
+def test_fused_vaegan_gradients_against_fp64_oracle(S, z, B):
+    """The fused VAE-GAN step (engine_gan.FusedVAEGANStep, split-bf16) at the golden fixture's shape (vaegan_64x64_z32_b4) and at
+    the benchmark shape (128x128, 16 images): every arena -- discriminator included -- against the fp64 oracle evaluated with the
+    plan's own ReLU masks and loss coefficients.  The golden test's gradient budgets (tests/test_gpu_engine_gan.py) stand on these
+    numbers.  Reference: models/networks.py:264-281, train.py:61-73."""
+    import vae_play_amd as V
+    from oracle import ref_cpu as O
+    from oracle import ref_vaegan as G
+    from vae_play_amd import optim
+    from vae_play_amd.engine_gan import FusedVAEGANStep
+    L = O.iter_level_for(S)
+    p0 = G.init_vaegan_params(S, z, seed=0)
+    batch = G.synthetic_batch(B, S, z)
+    net = V.VaeGan(S, z)
+    net.load_state_dict(p0, strict=True)
+    net = net.to(DEV).train()
+    opts = [optim.RMSprop(m.parameters(), lr=1e-4) for m in (net.encoder, net.decoder, net.discriminator, net.param_encoder)]
+    fused = FusedVAEGANStep(net, opts, B, S, lambda_mse=G.LAMBDA_MSE)
+    fused.forward_backward(*(t.to(DEV) for t in batch))
+    torch.cuda.synchronize()
+    c_disc, c_mse = fused.c_disc, fused.c_mse
+    g64, o64, m64 = _vaegan_total(p0, batch, S, torch.float64, c_disc, c_mse)
+    g32, _, _ = _vaegan_total(p0, batch, S, torch.float32, c_disc, c_mse)
+    for name, ours, ref in (("mus", fused.mu, o64["mus"]), ("logvar", fused.logvar, o64["logvar"]), ("x_tilde", fused.x_tilde, o64["x_tilde"]),
+                            ("disc_class", fused.disc_class, o64["disc_class"])):
+        e = record(f"vaegan_fused/out/{name}", _rel(ours.reshape(-1), ref.reshape(-1)))
+        assert e <= 2e-4, f"{name}: {e:.2e}"
+    mh = _gan_masks(fused, B, S, L)
+    assert [tuple(m.shape) for m in mh] == [tuple(m.shape) for m in m64]
+    units = sum(m.numel() for m in mh)
+    flips = sum(int((a != (b > 0)).sum()) for a, b in zip(mh, m64))
+    record("vaegan_fused/relu_mask_flips", flips)
+    record("vaegan_fused/relu_units", units)
+    assert flips <= max(8, 8 * U_MODE["bf16x3"] * units), f"{flips} of {units} ReLU masks differ from the fp64 forward pass"
+    g64m = _vaegan_total(p0, batch, S, torch.float64, c_disc, c_mse, masks=[m.double() for m in mh])[0] if flips else g64
+    params = dict(net.named_parameters())
+    bad, worst = [], {}
+    for n, g in g64m.items():
+        p = params[n]
+        ours = p._vp_arena.grad_view(p)
+        top = max(v.norm().item() for k, v in g64m.items() if k.split(".")[0] == n.split(".")[0])
+        if g.norm().item() < 1e-6 * top:           # a mathematically (near-)zero gradient tensor: round-off on both sides
+            continue
+        e_hip, e_raw, e_o32 = _rel(ours, g), _rel(ours, g64[n]), _rel(g32[n], g64[n])
+        arena = n.split(".")[0]
+        record(f"vaegan_fused/grad_vs_fp64_same_masks/{n}", e_hip)
+        record(f"vaegan_fused/grad_vs_fp64/{n}", e_raw)
+        bound = max(2 * e_o32, GAN_GRAD_FLOOR)
+        worst[arena] = max(worst.get(arena, 0.0), e_hip)
+        if e_hip > bound:
+            bad.append(f"{n}: HIP {e_hip:.2e} vs fp64 with the same masks ({e_raw:.2e} with fp64's own); fp32 oracle {e_o32:.2e}")
+    for arena, w in worst.items():
+        record(f"vaegan_fused/grad_vs_fp64_same_masks/worst/{arena}", w)
+    assert set(worst) == {"encoder", "decoder", "discriminator", "param_encoder"}
+    assert not bad, f"bound max(2 x fp32-oracle error, {GAN_GRAD_FLOOR:.0e}) exceeded ({flips} mask flips of {units}):\n" + "\n".join(bad)

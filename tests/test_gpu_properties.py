@@ -71,7 +71,6 @@ def test_conv_families_are_adjoint_and_bilinear_at_full_size(cfg, name, Cb, Cs, 
     assert err <= tol * 4, f"{name}: gather not linear ({err:.2e})"
     if precision == "bf16x3":
         _check_epilogue_statistics(name, x, p0, p1, y, Cb, Cs, Hs, B, cx)
-        _check_epilogue_bn_backward(name, x, p0, p1, y, Cb, Cs, Hs, B, cx)
 
 
 def _check_epilogue_statistics(name, x, p0, p1, y, Cb, Cs, Hs, B, cx):
@@ -108,57 +107,6 @@ def _check_epilogue_statistics(name, x, p0, p1, y, Cb, Cs, Hs, B, cx):
         assert ((rstd.double() - (v64 + 1e-5).rsqrt()).abs() * sig).max().item() <= 1e-5, f"{name} family {family}: rstd"
         assert ((mean - mean2).abs() / sig.float()).max().item() <= 1e-5 and ((rstd - rstd2).abs() * sig.float()).max().item() <= 1e-5
         assert ((rm - rm2).abs() / sig.float()).max().item() <= 1e-5 and ((rv - rv2).abs() / v64.float()).max().item() <= 1e-5, "running buffers"
-
-
-def _check_epilogue_bn_backward(name, x, p0, p1, y, Cb, Cs, Hs, B, cx):
-    """vp_conv5_*_bnbwd_bf16x3 + vp_bn_act_bwd_apply_split_f32 against vp_bn_act_bwd_split_f32 on the plain convolution's output:
-    the same dy bit for bit, the same masks (so dx differs only by the rounding of the two channel sums)."""
-    from vae_play_amd import _lib, ops
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(7 + Cb + Cs)
-    for family in (0, 1):
-        nbytes = lib.vp_conv5_stats_workspace_bytes(family, B, Hs, Hs, Cb, Cs, 2)
-        if not nbytes:
-            continue
-        ws = torch.empty(nbytes // 4, device=DEV)
-        if family == 0:
-            dy_ref, Cn, R = cx, Cs, B * Hs * Hs
-            inp, wq, name_, geom = ops.split_f32(x), p0, "vp_conv5_gather_bnbwd_bf16x3", (B, Hs, Hs, Cb, Cs, 2)
-        else:
-            dy_ref, Cn, R = ops.conv5_scatter_bf16x3(ops.split_f32(y), y.shape, p1, Cb, 2), Cb, B * 4 * Hs * Hs
-            inp, wq, name_, geom = ops.split_f32(y), p1, "vp_conv5_scatter_bnbwd_bf16x3", (B, Hs, Hs, Cs, Cb, 2)
-        # the BatchNorm layer whose output gradient the convolution produces: its input bx, saved statistics and affine pair
-        bx = (torch.randn(dy_ref.shape, generator=g) * 1.3 + 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
-        gamma, beta = (torch.rand(Cn, generator=g) + 0.5).to(DEV), (torch.randn(Cn, generator=g) * 0.3).to(DEV)
-        mean, rstd = ops.bn_stats(bx, 1e-5, 0.9, torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV))
-        dy = torch.empty_like(dy_ref)
-        sums, dga, dbe = torch.empty(2 * Cn, device=DEV), torch.empty(Cn, device=DEV), torch.empty(Cn, device=DEV)
-        _lib.call(name_, ops._pv(inp), ops._pv(wq), ops._p(dy), *geom, ops._p(bx), ops._p(mean), ops._p(rstd), ops._p(gamma), ops._p(beta),
-                  1, ops._p(sums), ops._p(dga), ops._p(dbe), ops._p(ws), nbytes, ops._stream())
-        assert torch.equal(dy, dy_ref), f"{name} family {family}: the BatchNorm-backward epilogue changed the convolution's output"
-        dx = torch.empty_like(dy)
-        _lib.call("vp_bn_act_bwd_apply_split_f32", ops._p(bx), ops._p(dy), ops._p(mean), ops._p(rstd), ops._p(gamma), ops._p(beta),
-                  ops._p(sums), ops._p(dx), None, R, Cn, 1, 0.0, 1, ops._stream())
-        # stand-alone three-pass kernel on the same inputs
-        dx2, dga2, dbe2 = torch.empty_like(dy), torch.empty(Cn, device=DEV), torch.empty(Cn, device=DEV)
-        nb2 = lib.vp_bn_workspace_bytes(R, Cn)
-        ws2 = torch.empty(nb2 // 4, device=DEV)
-        _lib.call("vp_bn_act_bwd_split_f32", ops._p(bx), ops._p(dy_ref), ops._p(mean), ops._p(rstd), ops._p(gamma), ops._p(beta),
-                  ops._p(dx2), None, ops._p(dga2), ops._p(dbe2), R, Cn, 1, 0.0, 1, ops._p(ws2), nb2, ops._stream())
-        # fp64 sums; torch's fp32 pre-activation may round differently from the kernels' fmaf for a unit within an ulp of zero
-        # (one flipped unit moves a channel sum by ~1/R of its absolute sum), hence the looser bound against fp64
-        bxd = bx.double()
-        xh = (bxd - mean.double().view(1, -1, 1, 1)) * rstd.double().view(1, -1, 1, 1)
-        mask = (torch.addcmul(beta.view(1, -1, 1, 1), gamma.view(1, -1, 1, 1), ((bx - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1))) > 0)
-        gd = dy_ref.double() * mask
-        sg, sgx = gd.sum(dim=(0, 2, 3)), (gd * xh).sum(dim=(0, 2, 3))
-        ng, ngx = gd.abs().sum(dim=(0, 2, 3)), (gd * xh).abs().sum(dim=(0, 2, 3))
-        assert ((dbe.double() - sg).abs() / ng).max().item() <= 2e-4, f"{name} family {family}: dbeta"
-        assert ((dga.double() - sgx).abs() / ngx).max().item() <= 2e-4, f"{name} family {family}: dgamma"
-        assert torch.equal(sums[:Cn], dbe) and torch.equal(sums[Cn:], dga)
-        assert ((dbe - dbe2).abs().double() / ng).max().item() <= 2e-6 and ((dga - dga2).abs().double() / ngx).max().item() <= 2e-6
-        err = ((dx - dx2).double().pow(2).sum().sqrt() / dx2.double().pow(2).sum().sqrt()).item()
-        assert err <= 1e-6, f"{name} family {family}: dx {err:.2e}"
 
 
 @pytest.mark.parametrize("C,H", [(64, 64), (64, 128), (512, 8)])

@@ -20,7 +20,6 @@ VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BU
 echo "mfma done"
 VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o t -- python3 $P > $O/fetch.log 2>&1 || exit 1
 VP_SIDE_WGRAD=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o t -- python3 $P > $O/write.log 2>&1 || exit 1
-VP_SIDE_WGRAD=0 VP_XCD_MAP=2 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_band -o t -- python3 $P > $O/fetch_band.log 2>&1 || exit 1
 echo "traffic done"
 find $O -name "*.csv" | head -40
 du -sh $O

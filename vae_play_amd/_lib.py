@@ -33,6 +33,7 @@ SIGNATURES = {
     "vp_conv5_scatter_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vp_conv5_wgrad_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "vp_conv5_wgrad_f32_cus": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "vp_pack_w_f32": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "vp_conv_gather_f32": (c_int, [P, P, P, P] + [c_int] * 10 + [P]),
     "vp_conv_scatter_f32": (c_int, [P, P, P] + [c_int] * 9 + [P]),
@@ -69,17 +70,16 @@ SIGNATURES = {
     "vp_conv5_scatter_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
     "vp_conv_scatter_f16": (c_int, [P, P, P] + [c_int] * 10 + [c_float, P]),
     "vp_conv5_wgrad_f16x2": (c_int, [P, P, P] + [c_int] * 6 + [c_float, P, c_size_t, P]),
+    "vp_conv5_wgrad_f16x2_cus": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_int, P, c_size_t, P]),
     "vp_conv_wgrad_f16x2": (c_int, [P, P, P] + [c_int] * 9 + [c_float, P, c_size_t, P]),
     "vp_conv5_stats_f16_workspace_bytes": (c_size_t, [c_int] * 7),
     "vp_conv5_gather_stats_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_conv5_scatter_stats_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_conv5_smallin_fwd_bf16x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_smallin_dgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "vp_conv5_gather_bnbwd_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [P, P, P, P, P, c_int, P, P, P, P, c_size_t, P]),
-    "vp_conv5_scatter_bnbwd_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [P, P, P, P, P, c_int, P, P, P, P, c_size_t, P]),
-    "vp_bn_act_bwd_apply_split_f32": (c_int, [P] * 9 + [c_int, c_int, c_int, c_float, c_int, P]),
     "vp_conv5_wgrad_bf16x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vp_conv5_wgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "vp_conv5_wgrad_bf16x3_cus": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "vp_wgrad_slab_reduce_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv3_small_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "vp_conv3_small_wgrad_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
@@ -125,6 +125,8 @@ SIGNATURES = {
     "vp_global_avgpool_bwd_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
     "vp_softmax_rows_fwd_f32": (c_int, [P, P, c_int, c_int, P]),
     "vp_softmax_rows_bwd_f32": (c_int, [P, P, P, c_int, c_int, P]),
+    "vp_cross_entropy_fwd_f32": (c_int, [P, P, P, P, c_int, c_int, P]),
+    "vp_cross_entropy_bwd_f32": (c_int, [P, P, P, P, c_int, c_int, P]),
     "vp_l1_mean_f32": (c_int, [P, P, c_size_t, P, P, c_size_t, P]),
     "vp_l1_mean_bwd_f32": (c_int, [P, P, P, P, P, c_size_t, P]),
     "vp_be_loss_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -19,7 +19,6 @@ inline BnGrid bn_grid(int R, int C) {
   BnGrid g;
   g.chunks_c = (C + BN_CH - 1) / BN_CH;
   int total = 1024;
-  if (const char* e = VP_GETENV("VP_BN_BLOCKS")) total = atoi(e);          // A/B knob
   int want = total / g.chunks_c;
   if (want < 1) want = 1;
   int maxr = (R + 63) / 64;   // at least ~64 rows per chunk
@@ -419,9 +418,7 @@ inline BnGrid bn_apply_grid(int R, int C) {
   BnGrid g;
   g.chunks_c = (C + BN_CH - 1) / BN_CH;
   int total = 4096;
-  if (const char* e = VP_GETENV("VP_BN_APPLY_BLOCKS")) total = atoi(e);    // A/B knob
   int rows_min = 4;                                                     // trips of 16 rows per workgroup, at least
-  if (const char* e = VP_GETENV("VP_BN_APPLY_TRIPS")) rows_min = atoi(e);
   int want = total / g.chunks_c;
   if (want < 1) want = 1;
   int maxr = (R + BN_TY * rows_min - 1) / (BN_TY * rows_min);
@@ -779,18 +776,6 @@ int vp_instnorm_act_bwd_split_f32(const float* x, const float* dy, const float* 
                                   int R, int C, int act, float slope, void* ws, size_t ws_bytes, vp_stream stream) {
   VP_REQUIRE(dx_split, "vp_instnorm_act_bwd_split_f32: null split output");
   return instnorm_act_bwd_impl(x, dy, mean, rstd, dx, dx_split, B, R, C, act, slope, ws, ws_bytes, stream);
-}
-
-int vp_bn_act_bwd_apply_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                                  const float* beta, const float* sums, float* dx, void* dx_split, int R, int C, int act, float slope,
-                                  int batch_stats, vp_stream stream) {
-  VP_REQUIRE(x && dy && mean && rstd && sums && (dx || dx_split) && R > 0 && C > 0, "vp_bn_act_bwd_apply_split_f32: bad arguments");
-  VP_REQUIRE(C % 4 == 0, "vp_bn_act_bwd_apply_split_f32: C must be a multiple of 4");
-  const float invR = batch_stats ? 1.f / (float)R : 0.f;
-  const BnGrid ga = bn_apply_grid(R, C);
-  hipLaunchKernelGGL(bn_act_bwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c), dim3(256), 0, (hipStream_t)stream, x, dy, mean, rstd, gamma, beta,
-                     sums, sums + C, dx, (u16_t*)dx_split, R, C, ga.rows_per_chunk, invR, act, slope);
-  return check_launch("vp_bn_act_bwd_apply_split_f32");
 }
 
 int vp_bn_small_fwd_f32(const float* x, int R, int C, float eps, float momentum, const float* gamma, const float* beta, float* mean,

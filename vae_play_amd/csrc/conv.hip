@@ -76,14 +76,14 @@ size_t vp_conv_wgrad_workspace_bytes(int B, int Hs, int Ws, int Hb, int Wb, int 
   size_t n = wgrad_slab_floats(g, wgrad_nsplit(g));
   if (const int bn = wgrad5_bn(g)) {
     int kper = 0;
-    const size_t n5 = wgrad5_slab_floats(g, bn, wgrad5_nsplit(g, bn, &kper, true));
+    const size_t n5 = wgrad5_slab_floats(g, bn, wgrad5_nsplit(g, bn, &kper));
     if (n5 > n) n = n5;
   }
   return n * sizeof(float);
 }
 
-int vp_conv_wgrad_f32(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
-                      int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream) {
+static int conv_wgrad_f32(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
+                          int Csmall, int ks, int stride, int max_cus, void* ws, size_t ws_bytes, vp_stream stream) {
   VP_REQUIRE(big && small && dw_ref && ws, "vp_conv_wgrad_f32: null pointer");
   int rc = conv_check("vp_conv_wgrad_f32", B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride);
   if (rc) return rc;
@@ -93,7 +93,7 @@ int vp_conv_wgrad_f32(const float* big, const float* small, float* dw_ref, int B
   if (narrow_wgrad_kind(g)) return narrow_wgrad_launch(big, small, dw_ref, g, (float*)ws, (hipStream_t)stream);
   if (const int bn = wgrad5f_kind(g, big, small)) {
     int kper = 0, slabs = 0;
-    const int ns5 = wgrad5_nsplit(g, bn, &kper, true);
+    const int ns5 = wgrad5_nsplit(g, bn, &kper, max_cus);
     wgrad5f_launch(big, small, (float*)ws, g, bn, ns5, kper, (hipStream_t)stream, &slabs);
     rc = check_launch("vp_conv_wgrad_f32(rows of taps)");
     if (rc) return rc;
@@ -105,6 +105,16 @@ int vp_conv_wgrad_f32(const float* big, const float* small, float* dw_ref, int B
   rc = check_launch("vp_conv_wgrad_f32(main)");
   if (rc) return rc;
   return slab_reduce_launch((const float*)ws, dw_ref, Csmall, Cbig, ns, (hipStream_t)stream, g.nt);
+}
+
+int vp_conv_wgrad_f32(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
+                      int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream) {
+  return conv_wgrad_f32(big, small, dw_ref, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, 0, ws, ws_bytes, stream);
+}
+
+int vp_conv5_wgrad_f32_cus(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Cbig, int Csmall,
+                           int stride, int max_cus, void* ws, size_t ws_bytes, vp_stream stream) {
+  return conv_wgrad_f32(big, small, dw_ref, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride, max_cus, ws, ws_bytes, stream);
 }
 
 /* 5x5 wrappers (big = stride * small) */

@@ -1,4 +1,5 @@
 // Split-bf16 ("bf16x3") convolution families: C ABI + the producers of split planes.
+#define VP_PCFG_LIBRARY 1
 #include "conv16_impl.h"
 
 namespace vp {
@@ -315,6 +316,11 @@ int vp_conv5_wgrad_bf16x3(const void* big_split, const void* small_split, float*
   return wgrad16<0>(big_split, small_split, dw_ref, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride, ws, ws_bytes, stream);
 }
 
+int vp_conv5_wgrad_bf16x3_cus(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,
+                              int Csmall, int stride, int max_cus, void* ws, size_t ws_bytes, vp_stream stream) {
+  return wgrad16<0>(big_split, small_split, dw_ref, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride, ws, ws_bytes, stream, 1.f, max_cus);
+}
+
 int vp_conv_wgrad_bf16x3(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
                          int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream) {
   return wgrad16<0>(big_split, small_split, dw_ref, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, ws, ws_bytes, stream);
@@ -463,70 +469,3 @@ int vp_conv5_smallout_bf16x3(const float* big, const float* w_p0, const float* b
 
 }
 
-// ---- BatchNorm-backward partial sums from the input-gradient convolution's epilogue --------------------------------------------
-namespace vp {
-// one 256-thread workgroup per channel: sum_g, sum_gx (fp64 over the groups) -> also the affine gradients dbeta, dgamma
-__global__ void __launch_bounds__(256) bn_bwd_slab_final_kernel(const float* __restrict__ slab, int G, int C, float* __restrict__ sum_g,
-                                                                float* __restrict__ sum_gx, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta) {
-  __shared__ double shs[4], shq[4];
-  const int c = blockIdx.x;
-  const float* sv = slab + ((size_t)0 * C + c) * G;
-  const float* qv = slab + ((size_t)1 * C + c) * G;
-  double S = 0.0, Q = 0.0;
-  for (int g = threadIdx.x; g < G; g += 256) { S += (double)sv[g]; Q += (double)qv[g]; }
-  S = wave_sum_d(S);
-  Q = wave_sum_d(Q);
-  if ((threadIdx.x & 63) == 0) { shs[threadIdx.x >> 6] = S; shq[threadIdx.x >> 6] = Q; }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  S = (shs[0] + shs[1]) + (shs[2] + shs[3]);
-  Q = (shq[0] + shq[1]) + (shq[2] + shq[3]);
-  sum_g[c] = (float)S;
-  sum_gx[c] = (float)Q;
-  if (dbeta) dbeta[c] = (float)S;
-  if (dgamma) dgamma[c] = (float)Q;
-}
-}  // namespace vp
-
-extern "C" {
-
-static int bnbwd_finish(const StatPlan& sp, const float* slab, float* sums, float* dgamma, float* dbeta, vp_stream stream) {
-  hipLaunchKernelGGL(bn_bwd_slab_final_kernel, dim3(sp.N), dim3(256), 0, (hipStream_t)stream, slab, sp.tiles_m * sp.gz, sp.N, sums, sums + sp.N,
-                     dgamma, dbeta);
-  return check_launch("vp_conv5_*_bnbwd_bf16x3(final)");
-}
-
-int vp_conv5_gather_bnbwd_bf16x3(const void* big_split, const void* w_p0_split, float* small_out, int B, int Hs, int Ws, int Cbig, int Csmall,
-                                 int stride, const float* bn_x, const float* bn_mean, const float* bn_rstd, const float* bn_gamma,
-                                 const float* bn_beta, int act, float* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                                 vp_stream stream) {
-  VP_REQUIRE(big_split && w_p0_split && small_out && bn_x && bn_mean && bn_rstd && sums && ws, "vp_conv5_gather_bnbwd_bf16x3: null pointer");
-  VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_RELU, "vp_conv5_gather_bnbwd_bf16x3: activation none|relu");
-  const StatPlan sp = stat_plan(0, B, Hs, Ws, Cbig, Csmall, stride);
-  VP_REQUIRE(sp.ok, "vp_conv5_gather_bnbwd_bf16x3: this shape cannot emit epilogue sums (vp_conv5_stats_workspace_bytes() == 0)");
-  if (ws_bytes < (size_t)2 * sp.N * sp.tiles_m * sp.gz * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_gather_bnbwd_bf16x3: workspace too small");
-  const BnBwdArgs bb = {bn_x, bn_mean, bn_rstd, bn_gamma, bn_beta, (float*)ws, act};
-  int rc = gather16_t<ProbF16>(big_split, w_p0_split, nullptr, small_out, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride,
-                               VP_ACT_NONE, true, stream, nullptr, &bb);
-  if (rc) return rc;
-  return bnbwd_finish(sp, (const float*)ws, sums, dgamma, dbeta, stream);
-}
-
-int vp_conv5_scatter_bnbwd_bf16x3(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Csmall, int Cbig,
-                                  int stride, const float* bn_x, const float* bn_mean, const float* bn_rstd, const float* bn_gamma,
-                                  const float* bn_beta, int act, float* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                                  vp_stream stream) {
-  VP_REQUIRE(small_split && w_p1_split && big_out && bn_x && bn_mean && bn_rstd && sums && ws, "vp_conv5_scatter_bnbwd_bf16x3: null pointer");
-  VP_REQUIRE(act == VP_ACT_NONE || act == VP_ACT_RELU, "vp_conv5_scatter_bnbwd_bf16x3: activation none|relu");
-  const StatPlan sp = stat_plan(1, B, Hs, Ws, Cbig, Csmall, stride);
-  VP_REQUIRE(sp.ok, "vp_conv5_scatter_bnbwd_bf16x3: this shape cannot emit epilogue sums (vp_conv5_stats_workspace_bytes() == 0)");
-  if (ws_bytes < (size_t)2 * sp.N * sp.tiles_m * sp.gz * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_scatter_bnbwd_bf16x3: workspace too small");
-  const BnBwdArgs bb = {bn_x, bn_mean, bn_rstd, bn_gamma, bn_beta, (float*)ws, act};
-  int rc = scatter16_t<ProbT16>(small_split, w_p1_split, big_out, B, Hs, Ws, Hs * stride, Ws * stride, Csmall, Cbig, 5, stride, true, stream,
-                                nullptr, &bb);
-  if (rc) return rc;
-  return bnbwd_finish(sp, (const float*)ws, sums, dgamma, dbeta, stream);
-}
-
-}

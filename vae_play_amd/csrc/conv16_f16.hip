@@ -1,5 +1,6 @@
 // fp16-pair ("f16") entry points of the split-operand convolution families: their own translation unit, so that the fp16 problem
 // descriptors (modes 1 and 2 of igemm16.h) are instantiated here and compile in parallel with conv16.hip's bf16 ones.
+#define VP_PCFG_LIBRARY 1
 #include "conv16_impl.h"
 
 #define VP_PRODUCTS_OK(what) VP_REQUIRE(products == 2 || products == 3, what ": products must be 2 or 3")
@@ -39,6 +40,11 @@ int vp_conv5_wgrad_f16x2(const void* big_split, const void* small_split, float* 
                          int Csmall, int stride, float out_scale, void* ws, size_t ws_bytes, vp_stream stream) {
   return wgrad16<2>(big_split, small_split, dw_ref, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride, ws, ws_bytes, stream, out_scale);
 }
+int vp_conv5_wgrad_f16x2_cus(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Cbig,
+                             int Csmall, int stride, float out_scale, int max_cus, void* ws, size_t ws_bytes, vp_stream stream) {
+  return wgrad16<2>(big_split, small_split, dw_ref, B, Hs, Ws, Hs * stride, Ws * stride, Cbig, Csmall, 5, stride, ws, ws_bytes, stream, out_scale, max_cus);
+}
+
 int vp_conv_wgrad_f16x2(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
                         int Csmall, int ks, int stride, float out_scale, void* ws, size_t ws_bytes, vp_stream stream) {
   return wgrad16<2>(big_split, small_split, dw_ref, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, ws, ws_bytes, stream, out_scale);

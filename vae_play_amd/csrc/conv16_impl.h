@@ -13,48 +13,44 @@
 using namespace vp;
 
 
-// VP_HALO=0 sends the narrow-channel layers back to the implicit-GEMM kernels (A/B runs)
 // XCD-aware tile order (igemm16.h): valid when the row-tile count is a multiple of 8 and there are >= 2 column tiles
 static int xcd_map_for(long M, long N, int gz, int ctile = 0) {
-  const char* e = VP_GETENV("VP_XCD_MAP");
-  const int mode = e ? atoi(e) : 1;
-  if (mode == 0) return 0;
   const Tile16 t = choose_tile16(M, N, gz, false, ctile);
   const long gx = (M + t.bm - 1) / t.bm, gy = (N + t.bn - 1) / t.bn;
-  if (mode == 2 || mode == 3) return (gx % 8 == 0 && gx >= 16) ? mode : 0;      // band orders (igemm16.h): any column-tile / z count
   return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
 }
 
-static bool halo_enabled() {
-  static const bool on = [] { const char* e = getenv("VP_HALO"); return !e || atoi(e) != 0; }();
-  return on;
-}
+static bool halo_enabled() { return true; }
 
-// layers with fewer output tiles than this split K in two (A/B knob VP_CONV_SPLIT_TILES)
-static long conv_split_tiles() {
-  const char* e = VP_GETENV("VP_CONV_SPLIT_TILES");
-  return e ? atol(e) : 384;
-}
+// layers with fewer output tiles than this split K in two
+static long conv_split_tiles() { return 384; }
 
 // Kernel choice for a plain 5x5 VAE layer on split planes: the pipelined LDS-DMA kernel (igemm16p.h, bit-identical results) takes
 // the shapes where its 256x256 eight-wave tile fills the chip -- N a multiple of 256 and at least one workgroup per CU, i.e. the
 // N >= 256 layers from ~128 images per GPU on (+5-10 % there, profiles/r02_notes.md); everything else stays on igemm16_kernel.
-// It also takes the small layers (see plan16).  VP_IGEMM16P=0 disables it, =2 keeps only the 256x256 rule (A/B),
-// VP_IGEMM16P_CFG=<n> forces configuration n of igemm16p.h wherever it applies (experiments).
-struct Launch16 { int pcfg, bm, bn; };
-static Launch16 plan16(long M, long N, int gz, int ctile, int nsplit, size_t plane_elems_a, size_t plane_elems_b, long kmin) {
+// It also takes the small layers and one big gather layer (see plan16).  VP_IGEMM16P=0 disables it, =2 keeps only the 256x256 rule (A/B).
+struct Launch16 { int pcfg, bm, bn; bool m16; };
+static bool pipelined_m16() {
+  static const bool on = [] { const char* e = getenv("VP_IGEMM16P_M16"); return !e || atoi(e) != 0; }();
+  return on;
+}
+static Launch16 plan16(long M, long N, int gz, int ctile, int nsplit, size_t plane_elems_a, size_t plane_elems_b, long kmin, bool stat = false) {
   const Tile16 t = choose_tile16(M, N, gz, false, ctile);
-  Launch16 l = {PCFG_NONE, t.bm, t.bn};
+  Launch16 l = {PCFG_NONE, t.bm, t.bn, false};
   static const int mode = [] { const char* e = getenv("VP_IGEMM16P"); return e ? atoi(e) : 1; }();
-  static const int forced = [] { const char* e = getenv("VP_IGEMM16P_CFG"); return e ? atoi(e) : 0; }();
   if (!mode || ctile % 32 != 0 || kmin / 32 < 4) return l;
   if (plane_elems_a >= ((size_t)1 << 29) || plane_elems_b >= ((size_t)1 << 29)) return l;      // 32-bit byte offsets of both planes
   int cfg = PCFG_NONE;
-  if (forced > PCFG_NONE && forced < PCFG_COUNT) cfg = nsplit == 1 ? forced : PCFG_NONE;
-  else if (nsplit == 1 && N % 256 == 0 && M >= 256 && ((M + 255) / 256) * (N / 256) * gz >= 256) cfg = PCFG_256x256_S2;
+  if (nsplit == 1 && N % 256 == 0 && M >= 256 && ((M + 255) / 256) * (N / 256) * gz >= 256) cfg = PCFG_256x256_S2;
   // the small layers (8x8 / 16x16 resolution at 32 images: M*N <= 1 M outputs, where igemm16_kernel runs 64x64 / 128x64 tiles with
   // K split in two): the pipelined 128x64 tile, same arithmetic bit for bit, is 4-10 % faster there (r02_a_kbench_m16_b32.log: c7b)
   else if (mode != 2 && M * N <= (1L << 20) && N >= 128 && M >= 128) cfg = PCFG_128x64_S3;
+  // round 3: the big gather layer where the pipelined kernel on the v_mfma_f32_16x16x32_bf16 form (`m16`) beats igemm16_kernel at 32
+  // images (profiles/r02_a_kbench_m16_b32.log: dec2.dgrad 176.0 -> 168.0 us on the 256x128 tile).  Same FLOPs per cycle, but the chip
+  // holds a higher clock on this MFMA shape (MI355X_MICROARCH.md, DVFS give-back 7); equal to the 32x32x16 form to rounding, not bit
+  // for bit (tests/test_gpu_kbench.py).  Never with the statistics epilogue, which reads the 32x32 accumulator layout
+  // (dec2.fwd, the other shape kbench favours, has one).  A/B knob VP_IGEMM16P_M16=0.
+  else if (mode != 2 && !stat && pipelined_m16() && nsplit == 1 && gz == 1 && N == 256 && M >= 16384 && M <= 65536 && ctile == 128) { cfg = PCFG_256x128_S3; l.m16 = true; }
   if (cfg == PCFG_NONE) return l;
   int bm, bn;
   pcfg_tile(cfg, bm, bn);
@@ -63,8 +59,6 @@ static Launch16 plan16(long M, long N, int gz, int ctile, int nsplit, size_t pla
   return l;
 }
 static int xcd_map_tile(long M, long N, int bm, int bn) {
-  const char* e = VP_GETENV("VP_XCD_MAP");
-  if (e && atoi(e) == 0) return 0;
   const long gx = (M + bm - 1) / bm, gy = (N + bn - 1) / bn;
   return (gx % 8 == 0 && gy >= 2) ? 1 : 0;
 }
@@ -81,12 +75,10 @@ static int scatter_nsplit(long M, int N, int Csmall, int stride, bool plain5) {
   return (plain5 && Csmall % 64 == 0 && tiles < conv_split_tiles() && 4 * Csmall >= 1024) ? 2 : 1;
 }
 
-struct BnBwdArgs { const float *x, *mean, *rstd, *gamma, *beta; float* slab; int act; };
-
 template <class PF>
 static int gather16_t(const void* big_split, const void* w_p0_split, const float* bias, float* small_out, int B, int Hs, int Ws, int Hb,
                       int Wb, int Cbig, int Csmall, int ks, int stride, int act, bool plain5, vp_stream stream, float* stat = nullptr,
-                      const BnBwdArgs* bb = nullptr, float alpha = 1.f) {
+                      float alpha = 1.f) {
   PF p;
   p.alpha = alpha;
   p.zero = vp_zero_page();
@@ -97,18 +89,17 @@ static int gather16_t(const void* big_split, const void* w_p0_split, const float
   p.M = B * Hs * Ws; p.N = Csmall; p.K = p.g.nt * Cbig;
   p.nsplit = gather_nsplit(p.M, p.N, p.K, Cbig, plain5, bias != nullptr, act);
   p.stat = stat;
-  if ((stat || bb) && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_gather_{stats,bnbwd}_bf16x3: this shape splits K");
-  if (bb) { p.bx = bb->x; p.bmean = bb->mean; p.brstd = bb->rstd; p.bgamma = bb->gamma; p.bbeta = bb->beta; p.bsum = bb->slab; p.bact = bb->act; }
+  if (stat && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_gather_stats_bf16x3: this shape splits K");
   p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
   if (p.nsplit == 2 && hipMemsetAsync(small_out, 0, (size_t)p.M * p.N * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_gather_bf16x3: memset failed");
   if constexpr (std::is_same<PF, ProbF16>::value) {
-    const Launch16 l = plan16(p.M, p.N, p.nsplit, Cbig, p.nsplit, p.big_plane, p.w_plane, p.k_per_split);
+    const Launch16 l = plan16(p.M, p.N, p.nsplit, Cbig, p.nsplit, p.big_plane, p.w_plane, p.k_per_split, stat != nullptr);
     if (l.pcfg != PCFG_NONE) {
       PF16 q;
       static_cast<ProbF16&>(q) = p;
       q.xcd_map = xcd_map_tile(p.M, p.N, l.bm, l.bn);
-      launch_igemm16p(q, l.pcfg, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig, true, false);
+      launch_igemm16p(q, l.pcfg, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig, true, l.m16);
       return check_launch("vp_conv_gather_bf16x3(pipelined)");
     }
   }
@@ -119,8 +110,7 @@ static int gather16_t(const void* big_split, const void* w_p0_split, const float
 
 template <class PT>
 static int scatter16_t(const void* small_split, const void* w_p1_split, float* big_out, int B, int Hs, int Ws, int Hb, int Wb, int Csmall,
-                       int Cbig, int ks, int stride, bool plain5, vp_stream stream, float* stat = nullptr, const BnBwdArgs* bb = nullptr,
-                       float alpha = 1.f) {
+                       int Cbig, int ks, int stride, bool plain5, vp_stream stream, float* stat = nullptr, float alpha = 1.f) {
   PT p;
   p.alpha = alpha;
   p.zero = vp_zero_page();
@@ -130,18 +120,17 @@ static int scatter16_t(const void* small_split, const void* w_p1_split, float* b
   p.out = big_out; p.M = B * Hs * Ws; p.N = Cbig;
   p.nsplit = scatter_nsplit(p.M, p.N, Csmall, stride, plain5);
   p.stat = stat;
-  if ((stat || bb) && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_scatter_{stats,bnbwd}_bf16x3: this shape splits K");
-  if (bb) { p.bx = bb->x; p.bmean = bb->mean; p.brstd = bb->rstd; p.bgamma = bb->gamma; p.bbeta = bb->beta; p.bsum = bb->slab; p.bact = bb->act; }
+  if (stat && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_scatter_stats_bf16x3: this shape splits K");
   if (p.nsplit == 2 &&
       hipMemsetAsync(big_out, 0, (size_t)B * p.g.Hb * p.g.Wb * Cbig * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv5_scatter_bf16x3: memset failed");
   if constexpr (std::is_same<PT, ProbT16>::value) {
-    const Launch16 l = plan16(p.M, p.N, stride * stride * p.nsplit, Csmall, p.nsplit, p.small_plane, p.w_plane, (long)stride * stride * Csmall);
+    const Launch16 l = plan16(p.M, p.N, stride * stride * p.nsplit, Csmall, p.nsplit, p.small_plane, p.w_plane, (long)stride * stride * Csmall, stat != nullptr);
     if (l.pcfg != PCFG_NONE && stride == 2) {
       PT16 q;
       static_cast<ProbT16&>(q) = p;
       q.xcd_map = xcd_map_tile(p.M, p.N, l.bm, l.bn);
-      launch_igemm16p(q, l.pcfg, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall, true, false);
+      launch_igemm16p(q, l.pcfg, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall, true, l.m16);
       return check_launch("vp_conv_scatter_bf16x3(pipelined)");
     }
   }
@@ -155,12 +144,10 @@ static int scatter16_t(const void* small_split, const void* w_p1_split, float* b
 // slow partial-tile loads), a 64-channel layer gets a 128-column tile's operand reuse.  (nt + 1) / 2 pairs instead of nt taps per split:
 // the pixel range is split twice as deep where the workspace allows.  A 64-channel SMALL side takes the 64x128 tile (wave tiles
 // 32x64) instead of 64x64 (32x32): with 128 | 256 | ... big channels directly (kind 4), with 64 big channels on tap pairs (kind 3) --
-// the font U-Net's full-resolution layers, 110 -> ~170 TFLOP/s (tools/microbench_font_layers.py).  A/B knob VP_WGRAD_PAIR=0.
+// the font U-Net's full-resolution layers, 110 -> ~170 TFLOP/s (tools/microbench_font_layers.py).
 //   kind 1: pairs, 64x64 tile (Cb = 32) | 2: pairs, 128x128 (Cb = 64, Cs % 128 == 0) | 3: pairs, 64x128 (Cb = 64, Cs % 64 == 0)
 //   kind 4: single taps, 64x128 tile (Cs % 128 == 64, Cb % 128 == 0)
 static inline int wgrad_wide_kind(const ConvGeom& g) {
-  static const bool on = !(getenv("VP_WGRAD_PAIR") && atoi(getenv("VP_WGRAD_PAIR")) == 0);
-  if (!on) return 0;
   const bool pair_nt = g.nt == 25 || g.nt == 9;
   if (pair_nt && g.Cb == 32 && g.Cs % 64 == 0) return 1;
   if (pair_nt && g.Cb == 64 && g.Cs % 128 == 0) return 2;
@@ -218,9 +205,9 @@ static inline int wgrad5_kind(const ConvGeom& g) {
 
 template <int MODE>
 static int wgrad16_rows(int bn, const void* big_split, const void* small_split, float* dw_ref, const ConvGeom& g, void* ws, size_t ws_bytes,
-                        vp_stream stream, float alpha) {
+                        vp_stream stream, float alpha, int max_cus) {
   int kper = 0;
-  const int ns = wgrad5_nsplit(g, bn, &kper);
+  const int ns = wgrad5_nsplit(g, bn, &kper, max_cus);
   if (ws_bytes < wgrad5_slab_floats(g, bn, ns) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv_wgrad_bf16x3: workspace too small");
   int slabs = 0;
   wgrad5_launch<MODE>(big_split, small_split, (float*)ws, g, bn, ns, kper, alpha, (hipStream_t)stream, &slabs);
@@ -275,8 +262,8 @@ static StatPlan stat_plan(int family, int B, int Hs, int Ws, int Cbig, int Csmal
     sp.R = sp.M * stride * stride;
   }
   const size_t act_plane = family == 0 ? (size_t)sp.M * stride * stride * Cbig : (size_t)sp.M * Csmall;
-  const Launch16 l = family == 0 ? plan16(sp.M, sp.N, sp.gz, Cbig, 1, act_plane, (size_t)Csmall * Cbig * 25, 25L * Cbig)
-                                 : plan16(sp.M, sp.N, sp.gz, Csmall, 1, act_plane, (size_t)Csmall * Cbig * 25, (long)stride * stride * Csmall);
+  const Launch16 l = family == 0 ? plan16(sp.M, sp.N, sp.gz, Cbig, 1, act_plane, (size_t)Csmall * Cbig * 25, 25L * Cbig, true)
+                                 : plan16(sp.M, sp.N, sp.gz, Csmall, 1, act_plane, (size_t)Csmall * Cbig * 25, (long)stride * stride * Csmall, true);
   sp.bm = (!x2 && l.pcfg != PCFG_NONE && !(family == 1 && stride != 2)) ? l.bm : choose_tile16(sp.M, sp.N, sp.gz, false, family == 0 ? Cbig : Csmall).bm;
   sp.tiles_m = (int)((sp.M + sp.bm - 1) / sp.bm);
   sp.ok = 1;
@@ -295,7 +282,7 @@ static int gather16(const void* big_split, const void* w_p0_split, const float* 
   const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
   if constexpr (F16 != 0) {    // fp16-pair planes, f16 = products per fragment pair: always the implicit-GEMM kernels (the halo kernels read bf16 pairs)
     VP_REQUIRE(alpha > 0.f, "vp_conv_gather_f16: out_scale must be positive");
-#define VP_G16(PF, P5) gather16_t<PF>(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, act, P5, stream, nullptr, nullptr, alpha)
+#define VP_G16(PF, P5) gather16_t<PF>(big_split, w_p0_split, bias, small_out, B, Hs, Ws, Hb, Wb, Cbig, Csmall, ks, stride, act, P5, stream, nullptr, alpha)
     if constexpr (F16 == 2) return plain5 ? VP_G16(ProbF16X, true) : VP_G16(ProbF16KX, false);
     else return plain5 ? VP_G16(ProbF16H, true) : VP_G16(ProbF16KH, false);
 #undef VP_G16
@@ -318,7 +305,7 @@ static int scatter16(const void* small_split, const void* w_p1_split, float* big
   const bool plain5 = ks == 5 && Hb == Hs * stride && Wb == Ws * stride;
   if constexpr (F16 != 0) {
     VP_REQUIRE(alpha > 0.f, "vp_conv_scatter_f16: out_scale must be positive");
-#define VP_S16(PT, P5) scatter16_t<PT>(small_split, w_p1_split, big_out, B, Hs, Ws, Hb, Wb, Csmall, Cbig, ks, stride, P5, stream, nullptr, nullptr, alpha)
+#define VP_S16(PT, P5) scatter16_t<PT>(small_split, w_p1_split, big_out, B, Hs, Ws, Hb, Wb, Csmall, Cbig, ks, stride, P5, stream, nullptr, alpha)
     if constexpr (F16 == 2) return plain5 ? VP_S16(ProbT16X, true) : VP_S16(ProbT16KX, false);
     else return plain5 ? VP_S16(ProbT16H, true) : VP_S16(ProbT16KH, false);
 #undef VP_S16
@@ -333,7 +320,7 @@ static int scatter16(const void* small_split, const void* w_p1_split, float* big
 
 template <int F16>
 static int wgrad16(const void* big_split, const void* small_split, float* dw_ref, int B, int Hs, int Ws, int Hb, int Wb, int Cbig,
-                   int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream, float alpha = 1.f) {
+                   int Csmall, int ks, int stride, void* ws, size_t ws_bytes, vp_stream stream, float alpha = 1.f, int max_cus = 0) {
   VP_REQUIRE(big_split && small_split && dw_ref && ws, "vp_conv_wgrad_bf16x3: null pointer");
   VP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cbig % 8 == 0 && Csmall % 8 == 0 && Cbig > 0 && Csmall > 0,
              "vp_conv_wgrad_bf16x3: channel counts must be multiples of 8");
@@ -343,9 +330,9 @@ static int wgrad16(const void* big_split, const void* small_split, float* dw_ref
   if (const int bn = wgrad5_kind(g)) {
     if constexpr (F16 != 0) {
       VP_REQUIRE(alpha > 0.f, "vp_conv_wgrad_f16x2: out_scale must be positive");
-      return wgrad16_rows<1>(bn, big_split, small_split, dw_ref, g, ws, ws_bytes, stream, alpha);
+      return wgrad16_rows<1>(bn, big_split, small_split, dw_ref, g, ws, ws_bytes, stream, alpha, max_cus);
     } else {
-      return wgrad16_rows<0>(bn, big_split, small_split, dw_ref, g, ws, ws_bytes, stream, 1.f);
+      return wgrad16_rows<0>(bn, big_split, small_split, dw_ref, g, ws, ws_bytes, stream, 1.f, max_cus);
     }
   }
   const int ns = wgrad_nsplit(g);

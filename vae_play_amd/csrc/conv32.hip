@@ -25,8 +25,7 @@ static void launch32_bk(const P& p, long M, long N, int gz, hipStream_t s, const
 // tile rule: the 16-bit kernels' (a K-tile is 2.7x more MFMA cycles here, so the same grids are at least as well fed)
 static Tile16 tile32(long M, long N, int gz) {
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
-  long minb = 384;
-  if (const char* e = VP_GETENV("VP_F32_TILE_BLOCKS")) minb = atol(e);     // A/B knob
+  const long minb = 384;
   if (M >= 128 && N >= 128 && blocks(128, 128) >= minb) return {128, 128};
   if (M >= 128 && N >= 64 && blocks(128, 64) >= minb) return {128, 64};
   return {64, 64};

@@ -938,7 +938,7 @@ int vp_adam_f32(float* p, const float* g, float* m, float* v, size_t n, float lr
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  static const int cap = [] { const char* e = getenv("VP_ADAM_BLOCKS"); return e ? atoi(e) : 256 * 64; }();
+  const int cap = 256 * 64;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, cap)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                      1.f - beta1, beta2, 1.f - beta2, eps, step_size, bc2_sqrt, grad_scale);
   return check_launch("vp_adam_f32");
@@ -951,7 +951,7 @@ int vp_adam_outer_f32(float* p, float* m, float* v, const float* A, const float*
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  static const int ti = [] { const char* e = getenv("VP_ADAM_OUTER_ROWS"); return e ? atoi(e) : 8; }();      // A/B knob: 8 (142 us on the 1024 x 32768 layer) | 16 (150 us)
+  const int ti = 8;      // rows per thread: 8 (142 us on the 1024 x 32768 layer) | 16 (150 us)
   const int TI = ti == 8 ? 8 : 16;
   const dim3 grid((unsigned)((Cn / 4 + 255) / 256), (unsigned)((R + TI - 1) / TI));
   VP_REQUIRE(grid.y <= 65535, "vp_adam_outer_f32: too many rows");
@@ -970,5 +970,57 @@ int vp_rmsprop_f32(float* p, const float* g, float* sq, size_t n, float lr, floa
   hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, p, g, sq, n, lr, alpha,
                      1.f - alpha, eps, grad_scale);
   return check_launch("vp_rmsprop_f32");
+}
+}
+
+// ---- F.cross_entropy(logits, labels) (mean over rows): train_BE_GAN.py:135,159, train_BE_font.py:109 ---------------------------
+// R rows of n logits, labels int64.  One workgroup; a thread owns whole rows (R = batch size, n = a handful of classes), the row
+// losses are summed in a fixed order: bit-reproducible.  prob[r][j] = softmax (kept for the backward pass).
+namespace vp {
+__global__ void __launch_bounds__(256) cross_entropy_fwd_kernel(const float* __restrict__ x, const long long* __restrict__ labels,
+                                                                float* __restrict__ loss, float* __restrict__ prob, int R, int n) {
+  __shared__ double part[256];
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float* xr = x + (size_t)r * n;
+    float m = xr[0];
+    for (int j = 1; j < n; ++j) m = fmaxf(m, xr[j]);
+    float ssum = 0.f;
+    for (int j = 0; j < n; ++j) ssum += __builtin_expf(xr[j] - m);
+    const float inv = 1.f / ssum;
+    for (int j = 0; j < n; ++j) prob[(size_t)r * n + j] = __builtin_expf(xr[j] - m) * inv;
+    const long long lb = labels[r];
+    const float xl = (lb >= 0 && lb < n) ? xr[lb] : 0.f;          // (an out-of-range label contributes lse only; the host checks)
+    acc += (double)((m + __builtin_logf(ssum)) - xl);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += part[i];
+    loss[0] = (float)(t / (double)R);
+  }
+}
+__global__ void cross_entropy_bwd_kernel(const float* __restrict__ prob, const long long* __restrict__ labels, const float* __restrict__ g,
+                                         float* __restrict__ dx, int R, int n) {
+  const float gs = g[0] / (float)R;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / n), j = (int)(i - (size_t)r * n);
+    dx[i] = gs * (prob[i] - (labels[r] == j ? 1.f : 0.f));
+  }
+}
+}  // namespace vp
+
+extern "C" {
+int vp_cross_entropy_fwd_f32(const float* logits, const long long* labels, float* loss, float* prob, int R, int n, vp_stream stream) {
+  VP_REQUIRE(logits && labels && loss && prob && R > 0 && n > 0, "vp_cross_entropy_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(vp::cross_entropy_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, loss, prob, R, n);
+  return vp::check_launch("vp_cross_entropy_fwd_f32");
+}
+int vp_cross_entropy_bwd_f32(const float* prob, const long long* labels, const float* gptr, float* dlogits, int R, int n, vp_stream stream) {
+  VP_REQUIRE(prob && labels && gptr && dlogits && R > 0 && n > 0, "vp_cross_entropy_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(vp::cross_entropy_bwd_kernel, dim3(vp::grid_for((size_t)R * n, 256)), dim3(256), 0, (hipStream_t)stream, prob, labels, gptr,
+                     dlogits, R, n);
+  return vp::check_launch("vp_cross_entropy_bwd_f32");
 }
 }

@@ -321,11 +321,9 @@ __global__ void __launch_bounds__(256) skinny_kn_kernel(const float* __restrict_
 // Split count of the skinny kernels (0: shape not eligible).  mode 0 / 1 as in vp_gemm_f32.
 inline int skinny_nsplit(int mode, long M, long N, long K) {
   if (mode > 1 || M > 64 || N < 128 || K % SK_KT) return 0;
-  if (const char* e = VP_GETENV("VP_GEMM_SKINNY")) if (atoi(e) == 0) return 0;   // A/B knob
   const long colblocks = (N + 127) / 128;
   const long unit = mode == 0 ? 256 : 4 * SK_KT;      // smallest K range worth a workgroup
   long blocks = 512;
-  if (const char* e = VP_GETENV("VP_SKINNY_BLOCKS")) blocks = atol(e);            // A/B knob
   long want = (blocks + colblocks - 1) / colblocks;
   long maxs = K / unit;
   if (maxs < 1) maxs = 1;
@@ -431,7 +429,7 @@ size_t vp_colsum_workspace_bytes(int R, int C) { return (size_t)colsum_chunks(R)
 
 int vp_colsum_f32(const float* x, float* out, int R, int C, void* ws, size_t ws_bytes, vp_stream stream) {
   VP_REQUIRE(x && out && ws && R > 0 && C > 0, "vp_colsum_f32: bad arguments");
-  static const bool small_on = [] { const char* e = getenv("VP_COLSUM_SMALL"); return !e || atoi(e) != 0; }();     // A/B knob
+  const bool small_on = true;
   if (R <= 64 && small_on) {      // a bias gradient over the batch rows: one launch, rows summed in order
     hipLaunchKernelGGL(colsum_small_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, R, C);
     return check_launch("vp_colsum_f32(small)");

@@ -88,11 +88,6 @@ struct ProbF16T {
   // sum((x - pivot)^2)} over the workgroup's valid rows, slab layout [3][N][groups], group = blockIdx.z * row tiles + row tile
   static constexpr bool HAS_STAT = true;
   float* stat = nullptr;
-  // BatchNorm-backward partial sums from the epilogue (nsplit == 1): this launch's output is the gradient dy that enters a
-  // BatchNorm(+ReLU) layer whose convolution output is bx (same layout as out).  Per workgroup and channel {sum g, sum g*xhat}
-  // with xhat = (x - mean) * rstd and g = dy * act'(gamma * xhat + beta): replaces bn_partial_kernel<1>'s read of dy and x.
-  const float* bx = nullptr; const float* bmean = nullptr; const float* brstd = nullptr;
-  const float* bgamma = nullptr; const float* bbeta = nullptr; float* bsum = nullptr; int bact = ACT_NONE;
   struct ZCtx { int k_begin, k_end; };
   struct ARow { int pix_base, h0, w0, valid; };
   VP_HD bool out_index(int m, int n, const ZCtx&, size_t& idx) const { idx = (size_t)m * N + n; return m < M && n < N; }
@@ -202,8 +197,6 @@ struct ProbT16T {
   int xcd_map;
   static constexpr bool HAS_STAT = true;
   float* stat = nullptr;     // see ProbF16T
-  const float* bx = nullptr; const float* bmean = nullptr; const float* brstd = nullptr;
-  const float* bgamma = nullptr; const float* bbeta = nullptr; float* bsum = nullptr; int bact = ACT_NONE;
   struct ZCtx { int k_begin, k_end, ph, pw, th, tw, r0h, r0w, bh, bw; };   // phase geometry as in problems.h ProbT
   VP_HD bool out_index(int m, int n, const ZCtx& z, size_t& idx) const {
     if (m >= M || n >= N) { idx = 0; return false; }
@@ -501,49 +494,6 @@ __device__ __forceinline__ void epilogue_stats32(float* __restrict__ stat, int g
   }
 }
 
-// BatchNorm-backward partial sums of the workgroup's output tile (see ProbF16T::bx): same reduction scheme as epilogue_stats32.
-// The pre-activation is evaluated with bn.hip's bn_pre() expression so that the mask is bit-consistent with the forward pass.
-template <class P, int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void epilogue_bnbwd32(const P& p, const typename P::ZCtx& z, int groups, int group, const f32x16_t (&acc)[TM][TN],
-                                                 unsigned char* lds, int m0, int n0, int wm, int wn, int li, int lh, int tid) {
-  float* red = reinterpret_cast<float*>(lds);      // [WM][BN][2]
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * (BN / WN) + 32 * j + li, n = n0 + col;
-    const bool nok = n < p.N;
-    const float mu = nok ? p.bmean[n] : 0.f, rs = nok ? p.brstd[n] : 0.f;
-    const float ga = (nok && p.bgamma) ? p.bgamma[n] : 1.f, be = (nok && p.bbeta) ? p.bbeta[n] : 0.f;
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        size_t idx;
-        if (p.out_index(m, n, z, idx)) {
-          const float xh = (p.bx[idx] - mu) * rs;
-          const float pre = __builtin_fmaf(ga, xh, be);
-          const float g = (p.bact == ACT_RELU && !(pre > 0.f)) ? 0.f : acc[i][j][r];
-          s += g;
-          q += g * xh;
-        }
-      }
-    s += __shfl_xor(s, 32, 64);
-    q += __shfl_xor(q, 32, 64);
-    if (lh == 0) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
-  }
-  __syncthreads();
-  if (tid < BN && n0 + tid < p.N) {
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-    const size_t n = (size_t)(n0 + tid);
-    p.bsum[(0 * (size_t)p.N + n) * groups + group] = s;
-    p.bsum[(1 * (size_t)p.N + n) * groups + group] = q;
-  }
-  __syncthreads();
-}
-
 template <class P, int BM, int BN, int WM, int WN, int BKT, bool FAST>
 __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -585,22 +535,6 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       const int hid = blockIdx.x + gridDim.x * blockIdx.y;
       const int r = hid & 7, q = hid >> 3;
       tx = r + 8 * (q / (int)gridDim.y);
-      ty = q % (int)gridDim.y;
-    } else if (p.xcd_map == 2) {
-      // band order: XCD r owns the contiguous band of row tiles [r * gx/8, (r+1) * gx/8) and walks it in order, and every
-      // (column tile, z slice) of one row tile -- the phases of a transposed convolution and the halves of a split K read the
-      // SAME activation rows -- runs back to back on that XCD: neighbouring row tiles share their halo rows in one L2
-      const int hid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-      const int r = hid & 7, q = hid >> 3, inner = (int)(gridDim.y * gridDim.z);
-      const int yz = q % inner;
-      tx = r * (int)(gridDim.x >> 3) + q / inner;
-      ty = yz % (int)gridDim.y;
-      tz = yz / (int)gridDim.y;
-    } else if (p.xcd_map == 3) {
-      // band order inside every z slice (phases / K halves stay separate launches in time, as in the default order)
-      const int hid = blockIdx.x + gridDim.x * blockIdx.y;
-      const int r = hid & 7, q = hid >> 3;
-      tx = r * (int)(gridDim.x >> 3) + q / (int)gridDim.y;
       ty = q % (int)gridDim.y;
     }
   }
@@ -828,9 +762,6 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
     if (p.stat)      // (workgroup-uniform) every wave is past its last LDS read: the loop ends with a barrier
       epilogue_stats32<BM, BN, WM, WN, TM, TN>(p.stat, (int)(gridDim.x * gridDim.z), (int)(tz * gridDim.x) + tx, p.M, p.N, acc, lds, m0, n0,
                                                wm, wn, li, lh, tid);
-    if (p.bsum)
-      epilogue_bnbwd32<P, BM, BN, WM, WN, TM, TN>(p, z, (int)(gridDim.x * gridDim.z), (int)(tz * gridDim.x) + tx, acc, lds, m0, n0,
-                                                  wm, wn, li, lh, tid);
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -849,204 +780,23 @@ struct Tile16 { int bm, bn; };   // wave grid: 2 x 2, or 4 x 1 for the 32-column
 
 inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false, int ctile = 0) {
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (long)gz; };
-  long MINB = 384;
-  if (const char* e = VP_GETENV("VP_TILE_BLOCKS")) MINB = atol(e);          // A/B knob
-  if (const char* e = VP_GETENV("VP_TILE_OVERRIDE")) {                      // A/B knob: "MxNxgz:BMxBN,..." per launch shape
-    char key[64];
-    snprintf(key, sizeof(key), "%ldx%ldx%d:", M, N, gz);
-    if (const char* q = strstr(e, key)) {
-      int bm = 0, bn = 0;
-      if (sscanf(q + strlen(key), "%dx%d", &bm, &bn) == 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) && !(bm == 64 && bn == 128))
-        return {bm, bn};
-    }
-  }
-  if (VP_GETENV("VP_TILE_LOG")) fprintf(stderr, "tile16 %ldx%ldx%d\n", M, N, gz);
+  const long MINB = 384;      // (per-shape tile searches on the VAE and VAE-GAN steps found nothing beyond noise: profiles/r02_notes.md section 7)
   // a 32-column operand (the 32-channel end of the last decoder block): 64-column tiles would idle half the MFMAs.
   // Unless k runs over 64-channel chunks (ctile = the gathered / scattered side's channel count) and the launch is large: the
   // 32-column tiles exist with 32-deep K-tiles only, and the 64x64 tile on 64-deep FAST K-tiles is 1.4-2.3x faster there even
-  // with half of its MFMA columns idle (tools/microbench_narrow_n.py: gather 5x5 s2 64 -> 32 channels 238 -> 106 us, the VAE-GAN
+  // with half of its MFMA columns idle (profiles/r02_g_narrow_n_microbench.log: gather 5x5 s2 64 -> 32 channels 238 -> 106 us, the VAE-GAN
   // discriminator's 64 -> 32 input gradient 252 -> 175 us; 32- and 40-channel chunks keep the narrow tiles: 134 vs 173 us).
-  static const bool deep_on = !(getenv("VP_NARROW_DEEP") && atoi(getenv("VP_NARROW_DEEP")) == 0);      // A/B knob
-  const bool deep = deep_on && ctile > 0 && ctile % 64 == 0 && (gz == 1 || M * gz >= (1L << 19));
+  const bool deep = ctile > 0 && ctile % 64 == 0 && (gz == 1 || M * gz >= (1L << 19));
   if (N <= 32 && M >= 128 && !deep) return (M >= 256 && blocks(256, 32) >= MINB) ? Tile16{256, 32} : Tile16{128, 32};
   if (M >= 128 && N >= 128 && blocks(128, 128) >= MINB) return {128, 128};
   if (M >= 128 && N >= 64 && blocks(128, 64) >= MINB) return {128, 64};
   return {64, 64};
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// LDS-DMA variant for the gather/scatter families (FAST shapes: channel count a multiple of 32).
-// Staging with global loads + ds_write_b128 costs ~830 LDS cycles per 128x128x64 tile (the VGPR->LDS store
-// path moves ~79 B/clk/CU) against 1536 MFMA cycles, and needs two barriers per tile.  Here every 16-B
-// chunk goes HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write):
-//   * K-tile = 32 elements -> 64-B rows per bf16 plane, stored UNPADDED (an LDS-DMA wave-instruction writes
-//     1 KiB = 16 consecutive rows, destination = wave-uniform base + lane*16);
-//   * bank conflicts are removed by an XOR swizzle applied to the per-lane SOURCE address and again on the
-//     fragment read: physical chunk = logical chunk ^ ((row >> 2) & 3)  (rows r, r+4, r+8, r+12 share a
-//     64-B segment of the 256-B bank row; the XOR sends their equal logical chunks to 4 different slots);
-//   * two LDS buffers, ONE barrier per K-tile: DMA(t+1) is issued before the MFMAs of tile t and retired by
-//     s_waitcnt vmcnt(0) + barrier after them;
-//   * out-of-range rows / padding taps source the zero page, so there is no predication anywhere.
-// ---------------------------------------------------------------------------------------------------------
-template <class P, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) igemm16_dma_kernel(const P p) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
-  static_assert(!P::A_KM && !P::B_KM, "DMA variant: k-contiguous operands only");
-  constexpr int BKT = 32;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;           // bytes per plane and buffer
-  constexpr int BUF = 2 * A_PLANE + 2 * B_PLANE;
-  constexpr int NIA = BM / 32, NIB = BN / 32;                    // DMA instructions per wave and tile
-  constexpr int NRA = (NIA + 1) / 2, NRB = (NIB + 1) / 2;        // distinct rows per lane (each feeds both planes)
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * BUF];
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  typedef const __attribute__((address_space(1))) void* g_ptr;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-  typename P::ZCtx z;
-  p.z_setup(blockIdx.z, z);
-
-  // DMA map: pair index pi = wave*NI + i; row block rb = pi >> 1 (16 rows), plane = pi & 1;
-  // lane -> row = rb*16 + lane/4, physical chunk = lane & 3
-  typename P::ARow ra[NRA];
-  typename P::BRow rb_[NRB];
-  int swa[NRA], swb[NRB];
-#pragma unroll
-  for (int j = 0; j < NRA; ++j) {
-    const int row = ((wave * NIA) / 2 + j) * 16 + (lane >> 2);
-    ra[j] = p.a_row(m0 + row, z);
-    swa[j] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;                // logical chunk -> element offset
-  }
-#pragma unroll
-  for (int j = 0; j < NRB; ++j) {
-    const int row = ((wave * NIB) / 2 + j) * 16 + (lane >> 2);
-    rb_[j] = p.b_row(n0 + row, z);
-    swb[j] = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
-  }
-  const u16* zsrc = reinterpret_cast<const u16*>(p.zero) + (lane & 3) * 8;
-
-  auto dma_tile = [&](int k0, int buf) {
-    unsigned char* base = lds + buf * BUF;
-#pragma unroll
-    for (int j = 0; j < NRA; ++j) {
-      size_t off;
-      const bool ok = p.template a_base<5>(ra[j], k0, z, off);
-      const u16* s0 = ok ? p.a_ptr() + off + swa[j] : zsrc;
-      const u16* s1 = ok ? p.a_ptr() + p.a_plane() + off + swa[j] : zsrc;
-      const int rblk = (wave * NIA) / 2 + j;
-      __builtin_amdgcn_global_load_lds((g_ptr)s0, (lds_ptr)(base + rblk * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((g_ptr)s1, (lds_ptr)(base + A_PLANE + rblk * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < NRB; ++j) {
-      size_t off;
-      const bool ok = p.template b_base<5>(rb_[j], k0, z, off);
-      const u16* s0 = ok ? p.b_ptr() + off + swb[j] : zsrc;
-      const u16* s1 = ok ? p.b_ptr() + p.b_plane() + off + swb[j] : zsrc;
-      const int rblk = (wave * NIB) / 2 + j;
-      __builtin_amdgcn_global_load_lds((g_ptr)s0, (lds_ptr)(base + 2 * A_PLANE + rblk * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((g_ptr)s1, (lds_ptr)(base + 2 * A_PLANE + B_PLANE + rblk * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int klen = z.k_end - z.k_begin;
-  const int nk = klen > 0 ? (klen + BKT - 1) / BKT : 0;
-  const int arow0 = wm * (BM / WM) + li;
-  const int brow0 = wn * (BN / WN) + li;
-  const int sw = (li >> 2) & 3;                                   // read-side swizzle: (row >> 2) & 3 of this lane's rows
-
-  if (nk > 0) {
-    dma_tile(z.k_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) dma_tile(z.k_begin + (kt + 1) * BKT, (kt + 1) & 1);
-    const unsigned char* A0 = lds + (kt & 1) * BUF;
-    const unsigned char* B0 = A0 + 2 * A_PLANE;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int coff = ((2 * s + lh) ^ sw) * 16;
-      bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const unsigned char* q = A0 + (arow0 + 32 * i) * 64 + coff;
-        ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(q));
-        al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(q + A_PLANE));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const unsigned char* q = B0 + (brow0 + 32 * j) * 64 + coff;
-        bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(q));
-        bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(q + B_PLANE));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = mfma_split<P::MODE>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed
-    __syncthreads();                                    // every wave's pieces have; buffer kt&1 is free again
-  }
-
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + wm * (BM / WM) + 32 * i + row;
-        const int n = n0 + wn * (BN / WN) + 32 * j + li;
-        p.store(m, n, acc[i][j][r], z);
-      }
-}
-
-template <class P>
-inline void launch_igemm16_dma(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0) {
-  Tile16 t = choose_tile16(M, N, gz, false, ctile);
-  dim3 block(256);
-  auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
-  if (t.bm == 128 && t.bn == 128) {
-    hipLaunchKernelGGL((igemm16_dma_kernel<P, 128, 128, 2, 2>), grid(128, 128), block, 0, stream, p);
-  } else if (t.bm == 128 && t.bn == 64) {
-    hipLaunchKernelGGL((igemm16_dma_kernel<P, 128, 64, 2, 2>), grid(128, 64), block, 0, stream, p);
-  } else {
-    hipLaunchKernelGGL((igemm16_dma_kernel<P, 64, 64, 2, 2>), grid(64, 64), block, 0, stream, p);
-  }
-}
-
-// Opt-in (VP_IGEMM16_DMA=1): in this one-tile-ahead form the DMA variant measured 10-25 % slower than the
-// register-staged BK=64 kernel on every layer (profiles/r01_c_notes.md): a 32-deep tile is 768 MFMA cycles,
-// too short to cover the DMA latency; it needs counted vmcnt + raw barriers + a third buffer to pay off.
-inline int igemm16_use_dma() {
-  const char* e = VP_GETENV("VP_IGEMM16_DMA");
-  return e ? atoi(e) : 0;
-}
-
 // K-tile depth: 64 for the gather/scatter families (half the barriers per MFMA), 32 for the weight
 // gradient (its [pixel][channel] LDS images at depth 64 leave one workgroup per CU).  Measured on
-// MI355X, profiles/; VP_IGEMM16_BK=32|64 overrides both for A/B runs.
+// MI355X, profiles/.
 inline int igemm16_bk(bool km, bool x2 = false) {
-  const char* e = km ? VP_GETENV("VP_IGEMM16_BK_W") : VP_GETENV("VP_IGEMM16_BK");
-  const int forced = e ? atoi(e) : 0;
-  if (forced == 32 || forced == 64) return forced;
   // the two-product fp16 mode stages three planes instead of four: the weight gradient's 64-deep K-tile then leaves two
   // workgroups per CU (61 KB each) and halves its barriers (measured -20 us per step, f16x2)
   return km ? (x2 ? 64 : 32) : 64;
@@ -1096,8 +846,7 @@ inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t strea
   } else {
     const Tile16 t0 = choose_tile16(M, N, gz, false, ctile);
     const bool narrow = t0.bn == 32;   // tiles that exist with 32-deep K-tiles only
-    if (ctile > 0 && ctile % 32 == 0 && igemm16_use_dma() && !narrow) launch_igemm16_dma<P>(p, M, N, gz, stream, ctile);
-    else if (ctile > 0 && ctile % 64 == 0 && bk == 64 && !narrow) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream, ctile);
+    if (ctile > 0 && ctile % 64 == 0 && bk == 64 && !narrow) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream, ctile);
     else if (ctile > 0 && ctile % 32 == 0) launch_igemm16_bk<P, 32, true>(p, M, N, gz, stream, ctile);   // 32-channel chunks
     else if (bk == 32 || narrow) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream, ctile);
     else launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream, ctile);

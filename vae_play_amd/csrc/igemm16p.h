@@ -316,11 +316,6 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) igemm16p_kernel(const P p)
     epilogue_stats32<BM, BN, WM, WN, TM, TN>(p.stat, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, p.M, p.N, acc, lds, m0, n0,
                                              wm, wn, li, lh, tid);
   }
-  if (p.bsum) {      // BatchNorm-backward partial sums of the tile (igemm16.h epilogue_bnbwd32)
-    __syncthreads();
-    epilogue_bnbwd32<P, BM, BN, WM, WN, TM, TN>(p, z, (int)(gridDim.x * gridDim.z), (int)(blockIdx.z * gridDim.x) + tx, acc, lds, m0, n0,
-                                                wm, wn, li, lh, tid);
-  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -469,16 +464,24 @@ inline void launch_igemm16p_k(const P& p, int cfg, long M, long N, int gz, hipSt
   int bm, bn;
   pcfg_tile(cfg, bm, bn);
   const dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz);
+  // The library (VP_PCFG_LIBRARY, set by conv16.hip) instantiates only what plan16 dispatches: buffer DMA, the 256x256 and 128x64
+  // tiles on the 32x32x16 MFMA and the 256x128 tile on the 16x16x32 form; tools/kbench compiles every configuration.
+#if defined(VP_PCFG_LIBRARY)
+#define VP_PCFG_ON(plain, q) (BUF && (M16 ? (q) : (plain)))
+#else
+#define VP_PCFG_ON(plain, q) true
+#endif
   switch (cfg) {
-    case PCFG_128x128_S3: hipLaunchKernelGGL((igemm16p_kernel<P, 128, 128, 2, 2, 3, KORD, 1, BUF, M16>), grid, dim3(256), 0, stream, p); break;
-    case PCFG_128x128_S2: hipLaunchKernelGGL((igemm16p_kernel<P, 128, 128, 2, 2, 2, KORD, 2, BUF, M16>), grid, dim3(256), 0, stream, p); break;
-    case PCFG_256x128_S3: hipLaunchKernelGGL((igemm16p_kernel<P, 256, 128, 4, 2, 3, KORD, 2, BUF, M16>), grid, dim3(512), 0, stream, p); break;
-    case PCFG_256x64_S3: hipLaunchKernelGGL((igemm16p_kernel<P, 256, 64, 4, 1, 3, KORD, 1, BUF, M16>), grid, dim3(256), 0, stream, p); break;
-    case PCFG_256x64_S2: hipLaunchKernelGGL((igemm16p_kernel<P, 256, 64, 4, 1, 2, KORD, 2, BUF, M16>), grid, dim3(256), 0, stream, p); break;
-    case PCFG_256x256_S2: hipLaunchKernelGGL((igemm16p_kernel<P, 256, 256, 2, 4, 2, KORD, 2, BUF, M16>), grid, dim3(512), 0, stream, p); break;
-    case PCFG_128x64_S3: hipLaunchKernelGGL((igemm16p_kernel<P, 128, 64, 2, 2, 3, KORD, 2, BUF, M16>), grid, dim3(256), 0, stream, p); break;
+    case PCFG_128x128_S3: if constexpr (VP_PCFG_ON(false, false)) hipLaunchKernelGGL((igemm16p_kernel<P, 128, 128, 2, 2, 3, KORD, 1, BUF, M16>), grid, dim3(256), 0, stream, p); break;
+    case PCFG_128x128_S2: if constexpr (VP_PCFG_ON(false, false)) hipLaunchKernelGGL((igemm16p_kernel<P, 128, 128, 2, 2, 2, KORD, 2, BUF, M16>), grid, dim3(256), 0, stream, p); break;
+    case PCFG_256x128_S3: if constexpr (VP_PCFG_ON(false, true)) hipLaunchKernelGGL((igemm16p_kernel<P, 256, 128, 4, 2, 3, KORD, 2, BUF, M16>), grid, dim3(512), 0, stream, p); break;
+    case PCFG_256x64_S3: if constexpr (VP_PCFG_ON(false, false)) hipLaunchKernelGGL((igemm16p_kernel<P, 256, 64, 4, 1, 3, KORD, 1, BUF, M16>), grid, dim3(256), 0, stream, p); break;
+    case PCFG_256x64_S2: if constexpr (VP_PCFG_ON(false, false)) hipLaunchKernelGGL((igemm16p_kernel<P, 256, 64, 4, 1, 2, KORD, 2, BUF, M16>), grid, dim3(256), 0, stream, p); break;
+    case PCFG_256x256_S2: if constexpr (VP_PCFG_ON(true, false)) hipLaunchKernelGGL((igemm16p_kernel<P, 256, 256, 2, 4, 2, KORD, 2, BUF, M16>), grid, dim3(512), 0, stream, p); break;
+    case PCFG_128x64_S3: if constexpr (VP_PCFG_ON(true, false)) hipLaunchKernelGGL((igemm16p_kernel<P, 128, 64, 2, 2, 3, KORD, 2, BUF, M16>), grid, dim3(256), 0, stream, p); break;
     default: break;
   }
+#undef VP_PCFG_ON
 }
 
 // ctile = channel count that k is decomposed by; KORD follows igemm16's dispatch (64-deep order when ctile % 64 == 0)

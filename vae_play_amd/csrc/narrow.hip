@@ -599,7 +599,7 @@ static bool slab_v4_ok(const float* slab, const float* dw_ref, size_t cc, int ns
 // variant: -1 = dispatch rule, 0 = scalar loads, 1 = 16-B loads (falls back to the rule's other choices when not applicable)
 int slab_reduce_variant_launch(const float* slab, float* dw_ref, int Cs, int Cb, int nsplit, hipStream_t s, int nt, int variant) {
   const size_t cc = (size_t)Cs * Cb, per = cc * nt;
-  static const bool v4_default = !(getenv("VP_SLAB_V4") && atoi(getenv("VP_SLAB_V4")) == 0);      // A/B knob
+  const bool v4_default = true;
   const bool v4 = variant < 0 ? v4_default : variant == 1;
   // (a 1x1 layer has one tap: the wide kernel would leave three of its four tap groups idle and walk every split serially)
   if (v4 && slab_v4_ok(slab, dw_ref, cc, nsplit, nt))

@@ -464,15 +464,9 @@ inline int wgrad_nsplit(const ConvGeom& g) {
   // 256 -> 4.61, 320 -> 4.56, 384 -> 4.35, 448 -> 4.37, 512 -> 4.44, 768 -> 4.47 ms/step); fewer splits also mean
   // smaller slabs for the reduction kernel
   long target = 384;
-  // per-shape search on the final schedule (tools/search_wgrad_ns.py): the single-tile layers (25 workgroups per split) keep
+  // per-shape search on the final schedule (round 2, profiles/r02_notes.md section 9): the single-tile layers (25 workgroups per split) keep
   // 16 splits, the 2- and 8-tile layers gain 0.6 % / 0.35 % of the step with 12 and 3 splits instead of 8 and 2
   if (tiles >= 50) target = 600;
-  if (const char* e = VP_GETENV("VP_WGRAD_BLOCKS")) target = atol(e);      // A/B knob
-  if (const char* e = VP_GETENV("VP_WGRAD_NS")) {                          // A/B knob: "CsxCb:ns,CsxCb:ns" overrides per shape
-    char key[48];
-    snprintf(key, sizeof(key), "%dx%d:", g.Cs, g.Cb);
-    if (const char* q = strstr(e, key)) { const int v = atoi(q + strlen(key)); if (v > 0) return v; }
-  }
   // tiny weights (<= 1024 entries per tap: the 1-8-channel predictor convolutions of the segmentation heads, run over
   // 256x256 images): one 32-row tile per tap does all the work of a million-pixel contraction, so split far deeper
   // (the slabs stay small); measured on tools/bench_be_heads.py
@@ -510,7 +504,6 @@ inline int gemm_nsplit(long M, long N, long K) {
   long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   if (tiles >= 128) return 1;
   long target = 384;
-  if (const char* e = VP_GETENV("VP_GEMM_BLOCKS")) target = atol(e);       // A/B knob
   long want = (target + tiles - 1) / tiles;
   long maxs = (K + 255) / 256;
   long s = want < maxs ? want : maxs;

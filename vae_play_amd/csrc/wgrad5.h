@@ -613,25 +613,16 @@ inline int wgrad5_bn(const ConvGeom& g) {
 }
 
 // pixel ranges: one workgroup per CU (the kernel holds 160 accumulators per lane at two waves per SIMD), i.e. ~256 work items
-inline int wgrad5_nsplit(const ConvGeom& g, int bn, int* k_per_split, bool f32 = false) {
+// `items` = work items (= CUs, the kernel owns one per work item) the launch may take; <= 0: the whole chip.  A caller that runs the
+// weight gradient beside other kernels leaves part of the chip to them: on the side stream of the fused step ~5/8 of the chip is
+// the measured optimum (step 3.588 ms with the one-tap kernels; rows of taps with 256 work items 3.52, 176: 3.479, 160: 3.455,
+// 144: 3.471, 128: 3.484, 96: 3.67 -- profiles/r03_notes.md): the main stream's kernels keep the rest instead of queueing behind
+// one-workgroup-per-CU launches, and the slabs shrink with the count.
+inline int wgrad5_nsplit(const ConvGeom& g, int bn, int* k_per_split, int items = 0) {
   const long K = (long)g.B * g.Hs * g.Ws;
   const long inner = (long)(g.Cs / 128) * (g.Cb / bn) * 5;
-  // Work items per launch.  The kernel owns a whole CU per workgroup (512 threads x 256 registers, 148 KB of LDS), so the count is
-  // also the number of CUs a launch takes: on the side stream of the fused step ~5/8 of the chip is the measured optimum (the main
-  // stream's kernels keep the rest instead of queueing behind one-workgroup-per-CU launches: step 3.588 ms with the one-tap kernels,
-  // 3.52 at 256 work items, 3.479 at 176, 3.455 at 160, 3.471 at 144, 3.484 at 128, 3.67 at 96 -- profiles/r03_notes.md), and the
-  // slabs shrink with it.
-  long target = 160;
-  if (const char* e = VP_GETENV("VP_WGRAD5_BLOCKS")) target = atol(e);       // A/B knob
-  if (f32) {             // the exact-f32 plan runs its weight gradients on the main stream: the whole chip
-    target = 256;
-    if (const char* e = VP_GETENV("VP_WGRAD5F_BLOCKS")) target = atol(e);    // A/B knob
-  }
-  if (const char* e = VP_GETENV("VP_WGRAD5_SPEC")) {                         // A/B knob: "CsxCbxK:blocks,..." per launch shape
-    char key[64];
-    snprintf(key, sizeof(key), "%dx%dx%ld:", g.Cs, g.Cb, K);
-    if (const char* q = strstr(e, key)) { const long v = atol(q + strlen(key)); if (v > 0) target = v; }
-  }
+  long target = items > 0 ? items : 256;
+  if (const char* e = VP_GETENV("VP_WGRAD5_BLOCKS")) target = atol(e);       // A/B knob: overrides the caller's count
   long ns = target / inner;
   if (ns < 1) ns = 1;
   const long maxs = K / 128 > 0 ? K / 128 : 1;                               // at least four K-tiles per split

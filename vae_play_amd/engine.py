@@ -43,27 +43,29 @@ class _Plan:
     def __init__(self):
         self.calls: List[list] = []
 
-    def add(self, name: str, *args, flops: float = 0.0, tag: str = "", side: Optional[int] = None):
+    def add(self, name: str, *args, flops: float = 0.0, tag: str = "", side: Optional[int] = None, side_args: Optional[dict] = None):
+        """``side_args`` = {argument index: (value on the main stream, value on the side stream)}: arguments that depend on where
+        the call ends up at run time (the weight gradients' CU budget: the whole chip alone, part of it beside the main stream)."""
         fn = getattr(_lib.load(), name)
         a = list(args) + [None]  # last argument of every entry point is the stream
-        self.calls.append([name, fn, a, len(a) - 1, flops, tag, side])
+        self.calls.append([name, fn, a, len(a) - 1, flops, tag, side, side_args])
 
     def add_first(self, name: str, *args, side: Optional[int] = None):
         fn = getattr(_lib.load(), name)
         a = list(args) + [None]
-        self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, "", side])
+        self.calls.insert(0, [name, fn, a, len(a) - 1, 0.0, "", side, None])
 
     def wait_side(self, k: int):
-        self.calls.append(["__wait_side__", None, [k], 0, 0.0, "", None])
+        self.calls.append(["__wait_side__", None, [k], 0, 0.0, "", None, None])
 
     def hook(self, key: str):
         """A named point of the plan: ``run(..., hooks={key: fn})`` calls ``fn(side)`` there (between two launches)."""
-        self.calls.append(["__hook__", None, [key], 0, 0.0, "", None])
+        self.calls.append(["__hook__", None, [key], 0, 0.0, "", None, None])
 
     def run(self, stream_ptr: int, timers: Optional[dict] = None, start: int = 0, stop: Optional[int] = None, side=None, hooks=None):
         """``side`` = a ``_SideCtx`` (side stream, its events, the fork event) or None (everything on the main stream)."""
         s = c_void_p(stream_ptr)
-        for ci, (name, fn, a, slot, flops, tag, sev) in enumerate(self.calls[start:stop], start):
+        for ci, (name, fn, a, slot, flops, tag, sev, sargs) in enumerate(self.calls[start:stop], start):
             if name == "__hook__":
                 if hooks is not None and a[0] in hooks:
                     hooks[a[0]](side)
@@ -74,6 +76,9 @@ class _Plan:
                     torch.cuda.current_stream().wait_event(side[1][a[0]])
                 continue
             on_side = side is not None and sev is not None
+            if sargs is not None:
+                for idx, (v_main, v_side) in sargs.items():
+                    a[idx] = v_side if on_side else v_main
             if on_side:
                 a[slot] = c_void_p(side[0].cuda_stream)
                 side.defer(name, fn, a, sev)                 # launched by the next flush (one fork for several launches)
@@ -115,7 +120,7 @@ class _SideCtx:
         self.stream = torch.cuda.Stream()
         self.events = [torch.cuda.Event() for _ in range(n_events)]
         self.fork = torch.cuda.Event()
-        self.batch = max(1, int(os.environ.get("VP_SIDE_BATCH", "1")))
+        self.batch = 1          # side launches per fork (batching them was measured slower, see above)
         self.pending: List[tuple] = []
 
     def __getitem__(self, i):
@@ -241,14 +246,18 @@ class FusedVAEStep:
         # two buffers; before a buffer is rewritten the main stream waits for the weight gradient that read it.
         x2 = self.precision == "f16x2"                 # fp16-pair planes + the *_f16x2 launches (same plan structure)
         x3 = self.precision in ("bf16x3", "f16x2")
+        # (exact-f32 plans keep everything on the main stream: with their weight gradients on the side stream -- fp32 output gradients
+        # rotating over two buffers, 128 / 160 / 192 CUs -- the step measured 8.39 / 8.06 / 8.03 ms against 7.89 ms in line,
+        # profiles/r03_notes.md: every fp32-MFMA kernel is compute-bound, there is no HBM-bound partner worth the contention)
         side_on = x3
         FMT = 1 if x2 else 0                           # VP_SPLIT_F16 | VP_SPLIT_BF16
         GS = self.grad_scale16 if x2 else 1.0          # scale of gradient planes; 1/GS in the launches that consume them
         n_side = [0]
 
         # fp16 plans: forward layers contract with three products (outputs keep the bf16x3 tolerance), backward layers with two
-        FWD_PRODUCTS = int(os.environ.get("VP_F16_FWD_PRODUCTS", "3"))     # A/B knob (2: the forward also on two MFMAs)
-        DEC_FWD_PRODUCTS = int(os.environ.get("VP_F16_DEC_FWD_PRODUCTS", str(FWD_PRODUCTS)))   # decoder forward only
+        # (the decoder forward on two products measured 3.51 -> 3.375 ms but 40x the ReLU-mask flips, every forward layer on two
+        # products puts mu outside the 1e-3 bar: profiles/r02_notes.md section 4)
+        FWD_PRODUCTS = DEC_FWD_PRODUCTS = 3
 
         def add_gather(plan, a_s, w_s, bias, out, geom, act, alpha=1.0, products=2, **kw):
             if x2:
@@ -262,11 +271,17 @@ class FusedVAEStep:
             else:
                 plan.add("vp_conv5_scatter_bf16x3", P(a_s), P(w_s), P(out), *geom, **kw)
 
+        # CU budget of a weight gradient: the whole chip on the main stream, WGRAD_SIDE_CUS beside the main stream's kernels
+        side_cus = int(os.environ.get("VP_WGRAD_SIDE_CUS", "160"))
+        main_cus = int(os.environ.get("VP_WGRAD_MAIN_CUS", "0"))      # (tests: the same budget on both streams = the same arithmetic)
+
         def add_wgrad(plan, big_s, small_s, dw, geom, ws, alpha=1.0, **kw):
             if x2:
-                plan.add("vp_conv5_wgrad_f16x2", P(big_s), P(small_s), P(dw), *geom, alpha, P(ws), ws.numel() * 4, **kw)
+                plan.add("vp_conv5_wgrad_f16x2_cus", P(big_s), P(small_s), P(dw), *geom, alpha, 0, P(ws), ws.numel() * 4,
+                         side_args={4 + len(geom): (main_cus, side_cus)}, **kw)
             else:
-                plan.add("vp_conv5_wgrad_bf16x3", P(big_s), P(small_s), P(dw), *geom, P(ws), ws.numel() * 4, **kw)
+                plan.add("vp_conv5_wgrad_bf16x3_cus", P(big_s), P(small_s), P(dw), *geom, 0, P(ws), ws.numel() * 4,
+                         side_args={3 + len(geom): (main_cus, side_cus)}, **kw)
 
         def side_slot():
             if not side_on:
@@ -275,8 +290,8 @@ class FusedVAEStep:
             return n_side[0] - 1
 
         # the batched weight re-pack (65 us, ~180 MB of traffic) also runs on the side stream, underneath the first
-        # encoder block, whose own (fp32, 3-channel) pack stays on the main stream; VP_SIDE_PACK=0 keeps it in line
-        k_pack = side_slot() if os.environ.get("VP_SIDE_PACK", "1") != "0" else None
+        # encoder block, whose own (fp32, 3-channel) pack stays on the main stream
+        k_pack = side_slot()
         first_pack_jobs = []
 
         def pack(weight, p0, p1, Cs, Cb, split, Cs_pad=0, first=False, bf16=False):
@@ -294,7 +309,7 @@ class FusedVAEStep:
             return x3 and cin % 8 == 0 and cout % 8 == 0
 
         fuse_stats = x3 and os.environ.get("VP_FUSE_BN_STATS", "1") != "0"
-        small_bn = os.environ.get("VP_BN_SMALL", "1") != "0"      # A/B knob: single-launch BatchNorm for <= 64 rows
+        small_bn = True            # single-launch BatchNorm for <= 64 rows (-33 us per step, profiles/r02_notes.md section 2)
 
         def bn_block(tag, x_buf, R, Cn, bn_mod, y_buf, y_split=None, conv=None):
             """stats + fused normalise/ReLU (fp32 and/or split output); returns the saved (mean, rstd).
@@ -338,36 +353,10 @@ class FusedVAEStep:
                         P(y_split), R, Cn, _ACT_RELU, 0.0)
             return mean, rstd, ws
 
-        # BatchNorm-backward sums from the input-gradient convolution's epilogue: measured NO gain on the concurrent schedule (the
-        # HBM-bound partial-sum pass it removes already hides under the side stream's weight gradient, profiles/r02_notes.md
-        # section 4), so it is off by default.  A/B knob: 0 | 1 | f (gather launches only) | t (scatter only) | k=<layer,...>
-        bnbwd_mode = os.environ.get("VP_FUSE_BN_BWD", "0")
-        fuse_bnbwd = x3 and not x2 and bnbwd_mode != "0"
-
-        def dgrad_bnbwd(plan, family, name, lead, geom, fl, tag, bn_x, mean, rstd, bn_mod, key):
-            """The input-gradient convolution whose output is dy of a BatchNorm + ReLU layer (conv output ``bn_x``): when the
-            launch shape can emit epilogue sums, ONE call (vp_conv5_*_bnbwd_bf16x3) also produces sum g, sum g*xhat and the
-            affine gradients, and the BatchNorm backward that follows only applies them.  Returns the sums buffer or None."""
-            qgeom = geom if family == 0 else (geom[0], geom[1], geom[2], geom[4], geom[3], geom[5])
-            nb = lib.vp_conv5_stats_workspace_bytes(family, *qgeom) if fuse_bnbwd else 0
-            if (bnbwd_mode == "f" and family != 0) or (bnbwd_mode == "t" and family != 1) or (bnbwd_mode.startswith("k=") and key not in bnbwd_mode[2:].split(",")):
-                nb = 0
-            if not nb:
-                return None
-            Cn = geom[4]                                        # channels of the convolution's output
-            sums, wsb = self._buf(f"{key}.bnsums", 2 * Cn), self._ws(f"{key}.bnbwdws", nb)
-            plan.add(name.replace("_bf16x3", "_bnbwd_bf16x3"), *lead, *geom, P(bn_x), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
-                     _ACT_RELU, P(sums), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), P(wsb), wsb.numel() * 4, flops=fl, tag=tag)
-            return sums
-
-        def bn_block_bwd(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None, sums=None):
-            if sums is None and dx_split is None and R <= 64 and Cn % 4 == 0 and small_bn:
+        def bn_block_bwd(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None):
+            if dx_split is None and R <= 64 and Cn % 4 == 0 and small_bn:
                 bwd.add("vp_bn_small_bwd_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(dx_buf),
                         P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1)
-                return
-            if sums is not None:
-                bwd.add("vp_bn_act_bwd_apply_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(sums),
-                        P(dx_buf), P(dx_split), R, Cn, _ACT_RELU, 0.0, 1)
                 return
             if x2 and dx_split is not None:      # gradient planes: fp16 pairs of GS * dx
                 bwd.add("vp_bn_act_bwd_split_fmt_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
@@ -390,7 +379,7 @@ class FusedVAEStep:
         enc_ch = [C] + [blk.conv.weight.shape[0] for blk in enc.conv]
         sp = [S // (2 ** i) for i in range(L + 1)]
         enc16 = [use16(enc_ch[i], enc_ch[i + 1]) for i in range(L)]
-        enc0_cols = x3 and C in (1, 3) and enc_ch[1] % 8 == 0 and os.environ.get("VP_ENC0_IM2COL", "1") != "0"
+        enc0_cols = x3 and C in (1, 3) and enc_ch[1] % 8 == 0
         enc_in = [x_nhwc]        # fp32 inputs (None when only the split copy exists)
         enc_in_s = [None]        # split inputs
         enc_rec = []
@@ -516,7 +505,7 @@ class FusedVAEStep:
             pack(fin.weight, fp0s, None, C, Cf, True)
             add_gather(fwd, dec_in_s[-1], fp0s, fin.bias, xt_nhwc, (B, S, S, Cf, C, 1), _ACT_SIGMOID, products=FWD_PRODUCTS,
                        flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
-        elif x3 and Cf == 64 and C in (1, 3) and os.environ.get("VP_TAPN", "1") != "0":
+        elif x3 and Cf == 64 and C in (1, 3):
             # split-bf16 on the matrix cores, taps folded into the MFMA columns (the exact-f32 plan keeps the VALU kernel)
             fwd.add("vp_conv5_smallout_bf16x3", P(dec_in[-1]), P(fp0), P(fin.bias), P(xt_nhwc), B, S, S, Cf, C, _ACT_SIGMOID,
                     flops=50.0 * B * S * S * Cf * C, tag="fin.fwd")
@@ -538,7 +527,7 @@ class FusedVAEStep:
         dlogit = self._buf("g.dlogit", n_pix)
         # final conv's input gradient: rows-in-K kernel of edge.hip (C = 1 | 3 image channels, 64 decoder channels), else the bf16x3
         # halo kernel with dlogit padded to 8 channels
-        fin_rowk = x3 and Cf == 64 and C in (1, 3) and os.environ.get("VP_ROWK", "1") != "0"
+        fin_rowk = x3 and Cf == 64 and C in (1, 3)
         fin16 = x3 and Cf % 8 == 0 and C < 8 and not fin_rowk
         if fin16:
             dlogit_s = self._sbuf("g.dlogit_s", B * S * S * 8)
@@ -550,7 +539,7 @@ class FusedVAEStep:
         ws_cs = self._ws("g.colsum.ws", lib.vp_colsum_workspace_bytes(B * S * S, C))
         bwd.add("vp_colsum_f32", P(dlogit), P(grad_of(fin.bias)), B * S * S, C, P(ws_cs), ws_cs.numel() * 4, side=side_slot())
         ws_wg = self._ws("g.wgrad.ws", self._max_wgrad_ws(enc_rec, dec_rec, Cf))
-        n_tapm = lib.vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(B, S, S, Cf, C) if (x3 and os.environ.get("VP_TAPM", "1") != "0") else 0
+        n_tapm = lib.vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(B, S, S, Cf, C) if x3 else 0
         if n_tapm:      # split-bf16 on the matrix cores, taps folded into the MFMA rows (csrc/edge.hip); its own slab workspace
             ws_fw = self._ws("g.finwgrad.ws", n_tapm)
             bwd.add("vp_conv5_smallout_wgrad_bf16x3", P(dec_in[-1]), P(dlogit), P(grad_of(fin.weight)), B, S, S, Cf, C, P(ws_fw),
@@ -570,9 +559,9 @@ class FusedVAEStep:
             bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         cur, other = gA, gB
         # split gradient (output of BN backward) for the 16-bit kernels, two buffers used alternately
-        # (VP_GS_BUFS = number of buffers in the rotation, default 2: with one buffer per layer the main stream never waits for a
-        # side-stream weight gradient before rewriting a buffer -- one cross-queue dependency less per layer)
-        n_gs = max(2, int(os.environ.get("VP_GS_BUFS", "2")))
+        # (one buffer per layer instead of the pair -- the main stream then never waits for a side-stream weight gradient before
+        # rewriting a buffer -- was measured neutral, 3.690 vs 3.691 ms: profiles/r02_notes.md section 7)
+        n_gs = 2
         gS2 = [self._sbuf(f"g.S{j}", big) for j in range(n_gs)] if x3 else [None] * n_gs
         self._grad_planes = gS2 if x2 else []
         gs_last = [None] * n_gs     # side event of the weight gradient that last read each buffer
@@ -584,7 +573,6 @@ class FusedVAEStep:
             if gs_last[k] is not None:
                 plan.wait_side(gs_last[k])
             return k
-        pend = None                 # BatchNorm-backward sums the previous input-gradient convolution already produced
         for i in range(L - 1, -1, -1):
             blk, Cin, Cout, Hs, p0, tbuf, mean, rstd, ws = dec_rec[i]
             R = B * 4 * Hs * Hs
@@ -592,20 +580,13 @@ class FusedVAEStep:
             if dec16[i]:
                 k = next_gs(bwd)
                 gS = gS2[k]
-                bn_block_bwd(tbuf, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS, sums=pend)  # gS = d t_i (split)
+                bn_block_bwd(tbuf, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)  # gS = d t_i (split)
                 gs_last[k] = side_slot()
                 add_wgrad(bwd, gS, dec_in_s[i], grad_of(blk.conv.weight), (B, Hs, Hs, Cout, Cin, 2), ws_wg, 1.0 / GS,
                           flops=fl, tag=f"dec{i}.wgrad", side=gs_last[k])
-                pend = None
-                if i > 0 and dec16[i - 1]:      # cur = d input_i is dy of block i-1's BatchNorm + ReLU
-                    nblk, _, _, _, _, ntbuf, nmean, nrstd, _ = dec_rec[i - 1]
-                    pend = dgrad_bnbwd(bwd, 0, "vp_conv5_gather_bf16x3", (P(gS), P(p0), P(cur)), (B, Hs, Hs, Cout, Cin, 2), fl,
-                                       f"dec{i}.dgrad", ntbuf, nmean, nrstd, nblk.bn, f"dec{i - 1}")
-                if pend is None:
-                    add_gather(bwd, gS, p0, None, cur, (B, Hs, Hs, Cout, Cin, 2), _ACT_NONE, 1.0 / GS,
-                               flops=fl, tag=f"dec{i}.dgrad")                              # cur = d input_i
+                add_gather(bwd, gS, p0, None, cur, (B, Hs, Hs, Cout, Cin, 2), _ACT_NONE, 1.0 / GS,
+                           flops=fl, tag=f"dec{i}.dgrad")                                  # cur = d input_i
             else:
-                assert pend is None
                 bn_block_bwd(tbuf, cur, other, R, Cout, blk.bn, mean, rstd, ws)          # other = d t_i
                 bwd.add("vp_conv5_wgrad_f32", P(other), P(dec_in[i]), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2,
                         P(ws_wg), ws_wg.numel() * 4, flops=fl, tag=f"dec{i}.wgrad")
@@ -638,14 +619,10 @@ class FusedVAEStep:
         bwd = bwd_b
         dh = self._buf("g.dh", B * 1024)
 
-        def bn_block_bwd2(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None, sums=None):
-            if sums is None and dx_split is None and R <= 64 and Cn % 4 == 0 and small_bn:
+        def bn_block_bwd2(x_buf, dy_buf, dx_buf, R, Cn, bn_mod, mean, rstd, ws, dx_split=None):
+            if dx_split is None and R <= 64 and Cn % 4 == 0 and small_bn:
                 bwd.add("vp_bn_small_bwd_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(dx_buf),
                         P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1)
-                return
-            if sums is not None:
-                bwd.add("vp_bn_act_bwd_apply_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias), P(sums),
-                        P(dx_buf), P(dx_split), R, Cn, _ACT_RELU, 0.0, 1)
                 return
             if x2 and dx_split is not None:      # gradient planes: fp16 pairs of GS * dx
                 bwd.add("vp_bn_act_bwd_split_fmt_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
@@ -666,7 +643,6 @@ class FusedVAEStep:
         self._bwd_b_dense_done = len(bwd.calls)
         bwd.add("vp_nchw_to_nhwc_f32", P(gA), P(gB), B, size, 8, 8)
         cur, other = gB, gA
-        pend = None
         for i in range(L - 1, -1, -1):
             blk, Cin, Cout, Hs, p1, c, mean, rstd, ws = enc_rec[i]
             R = B * Hs * Hs
@@ -675,13 +651,13 @@ class FusedVAEStep:
                 xcol, KC = self._enc0
                 k = next_gs(bwd)
                 gS = gS2[k]
-                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS, sums=pend)  # gS = d c_0 (split)
+                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)  # gS = d c_0 (split)
                 dwc = self._buf("enc0.dwc", Cout * KC)
                 ws0 = self._ws("enc0.wgws", lib.vp_conv_wgrad_bf16x3_workspace_bytes(B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1))
                 # the LAST weight gradient of the step stays on the main stream: on the side stream the join that follows it (and
                 # precedes the optimiser) finds both queues idle for ~18 us -- the latency of a dependency between two hardware
                 # queues (profiles/r02_notes.md) -- while here the side stream has long finished when the main stream joins it
-                last_main = os.environ.get("VP_LAST_WGRAD_MAIN", "1") != "0"
+                last_main = True
                 gs_last[k] = None if last_main else side_slot()
                 if x2:
                     bwd.add("vp_conv_wgrad_f16x2", P(xcol), P(gS), P(dwc), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, 1.0 / GS, P(ws0), ws0.numel() * 4,
@@ -693,24 +669,17 @@ class FusedVAEStep:
             elif enc16[i]:
                 k = next_gs(bwd)
                 gS = gS2[k]
-                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS, sums=pend)  # gS = d c_i (split)
+                bn_block_bwd2(c, cur, None, R, Cout, blk.bn, mean, rstd, ws, gS)  # gS = d c_i (split)
                 gs_last[k] = side_slot()
                 add_wgrad(bwd, enc_in_s[i], gS, grad_of(blk.conv.weight), (B, Hs, Hs, Cin, Cout, 2), ws_wg, 1.0 / GS,
                           flops=fl, tag=f"enc{i}.wgrad", side=gs_last[k])
-                pend = None
-                if i > 0:                       # cur = d a_{i-1} is dy of block i-1's BatchNorm + ReLU
-                    if enc16[i - 1] or (i == 1 and enc0_cols):
-                        nblk, _, _, _, _, nc, nmean, nrstd, _ = enc_rec[i - 1]
-                        pend = dgrad_bnbwd(bwd, 1, "vp_conv5_scatter_bf16x3", (P(gS), P(p1), P(cur)), (B, Hs, Hs, Cout, Cin, 2), fl,
-                                           f"enc{i}.dgrad", nc, nmean, nrstd, nblk.bn, f"enc{i - 1}")
-                    if pend is None:
-                        add_scatter(bwd, gS, p1, cur, (B, Hs, Hs, Cout, Cin, 2), 1.0 / GS,
-                                    flops=fl, tag=f"enc{i}.dgrad")                         # cur = d a_{i-1}
+                if i > 0:
+                    add_scatter(bwd, gS, p1, cur, (B, Hs, Hs, Cout, Cin, 2), 1.0 / GS,
+                                flops=fl, tag=f"enc{i}.dgrad")                             # cur = d a_{i-1}
                 if i == max(L - 2, 1):
                     # the gradients of encoder.conv[i:] (16.4 of the 17 MB of conv parameters at config 3) are issued: third bucket
                     self._bwd_b_enc_tail, self._enc_tail_first = len(bwd.calls), i
             else:
-                assert pend is None
                 bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)            # other = d c_i
                 # side stream only for the last layer of the walk (i == 0): nothing rewrites `other` after it
                 bwd.add("vp_conv5_wgrad_f32", P(enc_in[i]), P(other), P(grad_of(blk.conv.weight)), B, Hs, Hs, Cin, Cout, 2,

@@ -439,6 +439,8 @@ class FusedVAEGANStep:
         for r in dec1["blocks"]:
             nws = max(nws, lib.vp_conv5_wgrad_workspace_bytes(B, r[3], r[3], r[2], r[1], 2), lib.vp_conv5_wgrad_bf16x3_workspace_bytes(B, r[3], r[3], r[2], r[1], 2))
         ws_wg = self._ws("g.wgrad.ws", nws)                        # side-stream weight gradients run one after another
+        # CU budget of a weight gradient beside the main stream's kernels (csrc/wgrad5.h; 128 / 192 / 256: 5.78 / 5.91 / 6.04 ms)
+        side_cus = int(os.environ.get("VP_WGRAD_SIDE_CUS", "128"))
 
         def gather_block_bwd(rec, Bn, cur, gfn, need_dx, tag, pre_split=None):
             """conv5x5 s2 + BatchNorm + ReLU block, dy in ``cur`` (fp32 NHWC) -> dx in ``cur``"""
@@ -452,8 +454,8 @@ class FusedVAEGANStep:
             else:
                 pre_split(gS)
             gs_last[k] = side_slot()
-            bwd.add("vp_conv5_wgrad_bf16x3", P(in_s), P(gS), P(gfn(blk.conv.weight)), Bn, Hs, Hs, Cin, Cout, 2, P(ws_wg), ws_wg.numel() * 4,
-                    flops=fl, tag=f"{tag}.wgrad", side=gs_last[k])
+            bwd.add("vp_conv5_wgrad_bf16x3_cus", P(in_s), P(gS), P(gfn(blk.conv.weight)), Bn, Hs, Hs, Cin, Cout, 2, 0, P(ws_wg), ws_wg.numel() * 4,
+                    flops=fl, tag=f"{tag}.wgrad", side=gs_last[k], side_args={9: (0, side_cus)})
             if need_dx:
                 bwd.add("vp_conv5_scatter_bf16x3", P(gS), P(p1), P(cur), Bn, Hs, Hs, Cout, Cin, 2, flops=fl, tag=f"{tag}.dgrad")
 
@@ -526,8 +528,8 @@ class FusedVAEGANStep:
                 gS = gS2[k]
                 bn_bwd(tbuf, hA, None, gS, B * 4 * Hs * Hs, Cout, blk.bn, mean, rstd, ws, gfn)
                 gs_last[k] = side_slot()
-                bwd.add("vp_conv5_wgrad_bf16x3", P(gS), P(in_s), P(gfn(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2, P(ws_wg), ws_wg.numel() * 4,
-                        flops=fl, tag=f"{tag}{i}.wgrad", side=gs_last[k])
+                bwd.add("vp_conv5_wgrad_bf16x3_cus", P(gS), P(in_s), P(gfn(blk.conv.weight)), B, Hs, Hs, Cout, Cin, 2, 0, P(ws_wg), ws_wg.numel() * 4,
+                        flops=fl, tag=f"{tag}{i}.wgrad", side=gs_last[k], side_args={9: (0, side_cus)})
                 bwd.add("vp_conv5_gather_bf16x3", P(gS), P(p0), None, P(hA), B, Hs, Hs, Cout, Cin, 2, _ACT_NONE, flops=fl, tag=f"{tag}{i}.dgrad")
             bwd.add("vp_nhwc_to_nchw_f32", P(hA), P(hB), B, dsize, 8, 8)                             # hB = d db (B, F1)
             mean, rstd, ws = rec["fc"]

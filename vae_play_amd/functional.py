@@ -46,9 +46,9 @@ def get_conv_precision() -> str:
     return _PRECISION
 
 
-_SMALL3 = os.environ.get("VP_SMALL3", "1") != "0"           # A/B knob: VALU kernels for the few-channel 3x3 convolutions ("w": weight gradient only)
-_SMALL3_ALL = os.environ.get("VP_SMALL3", "1") not in ("0", "w")
-_BWD_SPLIT = os.environ.get("VP_BWD_SPLIT", "1") != "0"      # A/B knob: BatchNorm backward emits the split planes of dx
+_SMALL3 = True               # VALU kernels for the few-channel 3x3 convolutions (5.8 -> 3.8 ms per BE-heads step, profiles/r02_notes.md section 8)
+_SMALL3_ALL = True
+_BWD_SPLIT = True            # BatchNorm backward emits the split planes of dx
 
 
 def _split_of(x: torch.Tensor) -> torch.Tensor:
@@ -76,7 +76,7 @@ def _grad_out(param) -> Optional[torch.Tensor]:
     return arena.grad_view(param)
 
 
-_DIRECT_GRADS = os.environ.get("VP_DIRECT_GRADS", "1") != "0"
+_DIRECT_GRADS = True         # parameter gradients written straight into the arena slices (8.20 -> 8.00 ms per VAE-GAN step)
 
 
 _PACKED = {}     # (id(weight), layout) -> (weakref(weight), weight._version, optimiser epoch, data_ptr, device, packed tensor)
@@ -111,13 +111,12 @@ def _packed(fn, weight, want_p1: bool):
     return t
 
 
-_PACK_CACHE_ON = os.environ.get("VP_PACK_CACHE", "1") != "0"
+_PACK_CACHE_ON = True
 
 
 def first_conv_s1_edge(weight, stride: int) -> bool:
     """Does conv5x5(x, weight, bias, stride) run on the rows-in-K forward kernel (which takes a ReLU in its epilogue)?"""
-    return (_PRECISION == "bf16x3" and stride == 1 and weight.shape[1] in (1, 3) and weight.shape[0] in (32, 64)
-            and os.environ.get("VP_EDGE_AUTOGRAD", "1") != "0")
+    return (_PRECISION == "bf16x3" and stride == 1 and weight.shape[1] in (1, 3) and weight.shape[0] in (32, 64))
 
 
 def _use16(weight) -> bool:
@@ -134,7 +133,7 @@ class _Conv5(Function):
         ctx.cols = None
         Cs, Cb = weight.shape[0], weight.shape[1]
         if (_PRECISION == "bf16x3" and stride == 2 and Cb in (1, 3) and Cs % 8 == 0 and act == ACT_NONE and bias is None
-                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and os.environ.get("VP_EDGE_AUTOGRAD", "1") != "0"):
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
             # first conv on a 1- / 3-channel image (models/networks.py:14 via :55): its im2col written once as split planes, then a
             # 1x1 layer on the split-bf16 kernels for the forward pass and the weight gradient (as the fused step does)
             B, _, H, W = x.shape
@@ -171,7 +170,7 @@ class _Conv5(Function):
             # the image side of the final conv (64 -> 1 | 3 channels, models/networks.py:100-103) on the matrix cores: the edge
             # kernels of the fused step (taps in the MFMA columns / rows, a kernel row per k-step) instead of the VALU kernels
             ctx.edge = (_PRECISION == "bf16x3" and stride == 1 and weight.shape[1] == 64 and weight.shape[0] in (1, 3)
-                        and act in (ACT_NONE, ACT_SIGMOID) and os.environ.get("VP_EDGE_AUTOGRAD", "1") != "0")
+                        and act in (ACT_NONE, ACT_SIGMOID))
             if ctx.edge:
                 B, _, H, W = x.shape
                 y = ops.empty_cl(B, weight.shape[0], H, W, x)
@@ -228,8 +227,7 @@ class _Conv5(Function):
                     dyp = torch.zeros((B, H, W, 8), dtype=torch.float32, device=dy.device)
                     dyp[..., :Cs] = dy.permute(0, 2, 3, 1)
                     dx = ops.conv5_scatter_bf16x3(ops.split_f32(dyp), (B, 8, H, W), ops.pack_w5_p1_split_padded(weight, 8), Cb, 1)
-                elif (_PRECISION == "bf16x3" and Cb in (1, 3) and Cs in (32, 64) and ctx.stride == 1
-                      and os.environ.get("VP_EDGE_AUTOGRAD", "1") != "0"):
+                elif (_PRECISION == "bf16x3" and Cb in (1, 3) and Cs in (32, 64) and ctx.stride == 1):
                     # input gradient of a stride-1 first conv (the VAE-GAN discriminator's 1 -> 32, models/networks.py:160-163:
                     # its input is the decoder's output): dx[p] = sum_{tap, co} dy[p - tap + 2][co] W[co][ci][tap] is the
                     # "many channels -> 1 | 3" correlation of the tap-in-N kernel with the taps flipped
@@ -237,7 +235,7 @@ class _Conv5(Function):
                     wf = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cb, 25, Cs).contiguous()      # [ci][tap'][co]
                     dx = ops.empty_cl(B, Cb, H, W, dy)
                     _lib.call("vp_conv5_smallout_bf16x3", ops._p(dy), ops._p(wf), None, ops._p(dx), B, H, W, Cs, Cb, ACT_NONE, ops._stream())
-                elif _PRECISION == "bf16x3" and Cb < 8 and Cs % 8 == 0 and os.environ.get("VP_NARROW_DGRAD16", "1") != "0":
+                elif _PRECISION == "bf16x3" and Cb < 8 and Cs % 8 == 0:
                     # the image side of a FIRST conv whose input gradient is needed (the VAE-GAN discriminator's, models/
                     # networks.py:160-163: its input is the decoder's output): zero-pad the weight's input channels to 8,
                     # scatter on the split-bf16 kernels, keep the real channels.  The exact-f32 scatter to one output channel
@@ -705,6 +703,21 @@ class _L1Mean(Function):
         return da, db
 
 
+class _CrossEntropy(Function):
+    """F.cross_entropy(logits, labels) with torch's defaults (mean), on vp_cross_entropy_{fwd,bwd}_f32."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, prob = ops.cross_entropy_fwd(logits.contiguous(), labels.contiguous())
+        ctx.save_for_backward(prob, labels)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, labels = ctx.saved_tensors
+        return ops.cross_entropy_bwd(prob, labels.contiguous(), g.reshape(1).contiguous()), None
+
+
 class _BELoss(Function):
     """bce_weight * BCEWithLogits(x, t) (mean) + dice(sigmoid(x), t) as one reduction + one elementwise backward."""
 
@@ -834,6 +847,12 @@ def global_avg_pool(x):
 
 def self_attention(x, q, k, v, gamma):
     return _SelfAttention.apply(x, q, k, v, gamma)
+
+
+def cross_entropy(logits, labels):
+    """``F.cross_entropy(logits, labels)`` for (B, classes) logits and int64 class indices (train_BE_GAN.py:135,159: the
+    discriminator's type losses; train_BE_font.py:109): a HIP kernel, like every other loss of the steps."""
+    return _CrossEntropy.apply(logits, labels)
 
 
 def l1_loss(a, b):

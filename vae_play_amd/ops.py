@@ -412,6 +412,24 @@ def softmax_rows_fwd(x2d):
     return y
 
 
+def cross_entropy_fwd(logits2d: torch.Tensor, labels: torch.Tensor):
+    """F.cross_entropy (mean) of (R, n) logits against int64 labels: (loss (1,), softmax rows (R, n))."""
+    R, n = logits2d.shape
+    if labels.dtype != torch.int64 or labels.shape != (R,) or not labels.is_cuda:
+        raise _lib.VaePlayHipError("cross_entropy: labels must be an int64 device tensor of shape (rows,)")
+    loss = torch.empty(1, dtype=torch.float32, device=logits2d.device)
+    prob = torch.empty_like(logits2d)
+    _lib.call("vp_cross_entropy_fwd_f32", _p(logits2d), c_void_p(labels.data_ptr()), _p(loss), _p(prob), R, n, _stream())
+    return loss, prob
+
+
+def cross_entropy_bwd(prob: torch.Tensor, labels: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    R, n = prob.shape
+    dx = torch.empty_like(prob)
+    _lib.call("vp_cross_entropy_bwd_f32", _p(prob), c_void_p(labels.data_ptr()), _p(g), _p(dx), R, n, _stream())
+    return dx
+
+
 def softmax_rows_bwd(y2d, dy2d):
     R, n = y2d.shape
     dx = torch.empty_like(y2d)
