@@ -66,6 +66,17 @@ int vp_conv5_wgrad_f32(const float* big, const float* small, float* dw_ref,
 /* As vp_conv5_wgrad_f32 with a bound on the CUs the launch occupies (see vp_conv5_wgrad_bf16x3_cus; max_cus <= 0: the whole chip). */
 int vp_conv5_wgrad_f32_cus(const float* big, const float* small, float* dw_ref, int B, int Hs, int Ws, int Cbig, int Csmall,
                            int stride, int max_cus, void* ws, size_t ws_bytes, vp_stream stream);
+/* Exact-fp32 convolution + the statistics pass of the BatchNorm that follows it (models/networks.py:14-16,38-40) in one call, as
+ * vp_conv5_*_stats_bf16x3: {pivot, sum(x - pivot), sum((x - pivot)^2)} per (workgroup, channel) from the fp32 accumulators, one
+ * finaliser launch for mean / rstd / running statistics (momentum semantics of torch).  vp_conv5_stats_f32_workspace_bytes() == 0:
+ * the shape cannot emit them (it splits K, or does not take the fast fp32 path) -- use vp_conv5_*_f32 + vp_bn_stats_f32. */
+size_t vp_conv5_stats_f32_workspace_bytes(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int stride);
+int vp_conv5_gather_stats_f32(const float* big, const float* w_p0, float* small_out, int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
+                              float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var, void* ws,
+                              size_t ws_bytes, vp_stream stream);
+int vp_conv5_scatter_stats_f32(const float* small, const float* w_p1, float* big_out, int B, int Hs, int Ws, int Csmall, int Cbig, int stride,
+                               float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var, void* ws,
+                               size_t ws_bytes, vp_stream stream);
 
 /* ---- k x k generalisation (ks = 1, 3 or 5, padding (ks-1)/2, stride 1 or 2) -------------------------------------
  * The conv/norm/act vocabulary of models/blocks.py:5-34 (nn.Conv2d(k, stride, padding=(k-1)//2)); same three families.
@@ -374,6 +385,13 @@ int vp_bn_act_bwd_split_fmt_f32(const float* x, const float* dy, const float* me
                                 const float* gamma, const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta,
                                 int R, int C, int act, float slope, int batch_stats, int fmt, float scale,
                                 void* ws, size_t ws_bytes, vp_stream stream);
+/* the same with a sticky saturation flag: *saturated (device int, owned and zeroed by the caller) is set to 1 when fmt = fp16 pairs and
+ * |scale * dx| exceeds fp16's range (65504) somewhere -- the planes then hold clamped values; engine.FusedVAEStep(precision="f16x2")
+ * reads the flag in sync_counters() and asks for a smaller grad_scale16 */
+int vp_bn_act_bwd_split_fmt_sat_f32(const float* x, const float* dy, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta,
+                                    int R, int C, int act, float slope, int batch_stats, int fmt, float scale, int* saturated,
+                                    void* ws, size_t ws_bytes, vp_stream stream);
 int vp_im2col5s2_split_fmt_f32(const float* x, void* out_split, int B, int C, int Hb, int Wb, int nchw, int fmt, vp_stream stream);
 int vp_pack_w_im2col5_split_fmt(const float* w_ref, void* out_split, int Cout, int C, int fmt, vp_stream stream);
 /* the three families; arguments as the *_bf16x3 entry points plus products (2 | 3) and out_scale (workspace queries of the weight

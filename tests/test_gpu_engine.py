@@ -4,7 +4,7 @@ when replayed from a captured hipGraph."""
 import pytest
 import torch
 
-from tests.util import NORTH_STAR_RTOL, assert_close, load_golden, record, t
+from tests.util import RAW_GRAD_L2, SAMPLE_FACTOR, NORTH_STAR_RTOL, assert_close, load_golden, record, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -66,8 +66,11 @@ def test_fused_step_against_reference_golden(name, precision):
                 assert gerr <= budget, f"grad l2 {n}: {gerr:.2e} > {budget:.0e}"
                 idx = O.sample_indices(gr.numel())
                 d = (gr.flatten()[idx].double() - t(g[f"grad_samples/{n}"])).abs().max().item()
-                sample_tol = {"f32": tol, "bf16x3": 5e-3, "f16x2": 5e-3}[precision]
-                assert d <= sample_tol * 30 * max(l2 / gr.numel() ** 0.5, 1e-12), f"grad samples {n}"
+                # samples: SAMPLE_FACTOR x the mode's ASSERTED raw l2 bound (tests/util.py, tests/test_gpu_grad_accuracy.py), in units of
+                # the tensor's RMS -- 0.03 RMS in exact fp32, 0.15 RMS in the split modes
+                rms = max(l2 / gr.numel() ** 0.5, 1e-12)
+                record(f"grad_sample_over_rms/{n}", d / rms)
+                assert d <= SAMPLE_FACTOR[precision] * RAW_GRAD_L2[precision] * rms, f"grad samples {n}: {d / rms:.2e} RMS"
             sd = vae.state_dict()
             for k in g:
                 if k.startswith("bn/"):

@@ -4,7 +4,7 @@ autograd path when both take their BatchNorm statistics from the same kernels; N
 import pytest
 import torch
 
-from tests.util import NORTH_STAR_RTOL, assert_close, load_golden, record, t
+from tests.util import GAN_RAW_GRAD_L2, GAN_SAMPLE_FACTOR, NORTH_STAR_RTOL, assert_close, load_golden, record, t
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -116,8 +116,8 @@ def test_fused_vaegan_step_equals_autograd_path(S, z, B, fuse_stats, monkeypatch
         assert 0 < d <= 10.5e-4, d
 
 
-@pytest.mark.parametrize("name,l2_budget,sample_budget", [("vaegan_32x32_z16_b4", 3e-3, 0.03), ("vaegan_64x64_z32_b4", 2e-2, 0.75)])
-def test_fused_vaegan_step_against_reference_golden(name, l2_budget, sample_budget):
+@pytest.mark.parametrize("name", ["vaegan_32x32_z16_b4", "vaegan_64x64_z32_b4"])
+def test_fused_vaegan_step_against_reference_golden(name):
     """Outputs, losses and BatchNorm buffers of the reference's first step at NORTH_STAR_RTOL; the encoder / decoder / param_encoder
     gradients at the split-bf16 mode's batch-4 budget (the discriminator's net gradient is 1e-6 of its cancelling terms in the
     reference's five-pass accumulation: compared against the one-pass autograd path above instead).
@@ -133,6 +133,10 @@ def test_fused_vaegan_step_against_reference_golden(name, l2_budget, sample_budg
     from vae_play_amd.engine_gan import FusedVAEGANStep
     g = load_golden(name)
     S, z, B = (int(g[k]) for k in ("meta_S", "meta_z", "meta_B"))
+    # budgets: a tensor's norm within the raw (own-mask) l2 bound that tests/test_gpu_grad_accuracy.py ASSERTS for this plan against
+    # the fp64 oracle (x 1), its samples within GAN_SAMPLE_FACTOR x that bound of the tensor's RMS (tests/util.py)
+    l2_budget = GAN_RAW_GRAD_L2[S]
+    sample_budget = GAN_SAMPLE_FACTOR * l2_budget
     net, opts = _build(S, z)
     x, targets, eps, z_p = (t(g[k]).to(DEV) for k in ("x", "targets", "eps", "z_p"))
     fused = FusedVAEGANStep(net, opts, B, S, lambda_mse=G.LAMBDA_MSE)
@@ -165,6 +169,7 @@ def test_fused_vaegan_step_against_reference_golden(name, l2_budget, sample_budg
             continue
         idx = O.sample_indices(gr.numel())
         d = (gr.flatten()[idx].double() - t(g[f"grad_samples/{n}"])).abs()
+        record(f"grad_sample_over_rms/{n}", d.max().item() / scale)
         assert d.max().item() <= sample_budget * scale, f"grad samples {n}: {d.max().item()} vs rms {scale}"
         rel = abs(gr.double().pow(2).sum().sqrt().item() - l2) / (l2 + 1e-30)
         record(f"grad_l2_rel/{n}", rel)

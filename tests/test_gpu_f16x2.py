@@ -139,6 +139,7 @@ def test_engine_reports_saturated_gradient_planes():
     vae, opt, fused, p0, L = build(C, S, z, B, precision="f16x2")
     fused.forward_backward(x.to(DEV), eps.to(DEV))
     assert fused.f16_saturated() == 0
+    fused.sync_counters()                                  # the sticky device flag is clear: no exception
     g_ok = {n: q.grad.detach().clone() for n, q in vae.named_parameters()}
     vae2 = V.VAE(S, z, C, init_rule=False)
     vae2.load_state_dict(p0)
@@ -147,6 +148,11 @@ def test_engine_reports_saturated_gradient_planes():
     bad = engine.FusedVAEStep(vae2, opt2, B, S, C, precision="f16x2", grad_scale16=float(2 ** 40))
     bad.forward_backward(x.to(DEV), eps.to(DEV))
     assert bad.f16_saturated() > 0
+    # ... and the producers raised the device-side flag: sync_counters() reports it once, then the flag is clear again
+    from vae_play_amd._lib import VaePlayHipError
+    with pytest.raises(VaePlayHipError, match="saturated"):
+        bad.sync_counters()
+    bad.sync_counters()
     # ... and a smaller power of two changes nothing but rounding
     vae3 = V.VAE(S, z, C, init_rule=False)
     vae3.load_state_dict(p0)

@@ -49,29 +49,15 @@ def main():
         out = step.step(feature, imgs, bimgs, eimgs, labels)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    # roofline of the iteration as a whole against HBM: the step is a chain of small kernels (3x3 convolutions with 1 - 64 channels at
-    # full resolution, BatchNorm, bilinear upsampling, losses), none of which is MFMA-bound; algorithmic bytes = every activation of
-    # both networks written once and read once per direction (fp32), parameters and optimiser state (28 B per parameter)
-    n_par = sum(p.numel() for p in G.parameters()) + sum(p.numel() for p in D.parameters())
-    act = []
-    hooks = [m.register_forward_hook(lambda mod, i, o: act.append(o.numel()) if torch.is_tensor(o) else None)
-             for net in (G, D) for m in net.modules() if not list(m.children())]
-    with torch.no_grad():
-        preds = G(feature)
-        D(imgs, preds["masks"].sigmoid(), preds["edges"].sigmoid())
-    for h in hooks:
-        h.remove()
-    # G runs twice and D four times per iteration; forward writes + reads, backward reads + writes of the differentiated passes
-    bytes_alg = 4.0 * sum(act) * (2 + 4) / 2 * 2 + 28.0 * n_par
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import op_roofline
+    roof = op_roofline.roofline(op_roofline.trace(lambda: step.step(feature, imgs, bimgs, eimgs, labels), 2))
     out_rec = {"metric": "images/sec (train_BE_GAN.py:131-165 iteration below the backbone)", "value": round(a.batch / dt, 1), "unit": "images/sec",
                "ms_per_step": round(dt * 1e3, 3), "n_gpus": 1, "higher_is_better": True, "dtype": a.precision, "data": "synthetic",
                "config": {"workload": f"ComposeNet heads ({a.feat} -> 64 ch) + Discriminator, {a.img}x{a.img}, batch {a.batch}, D step + G step",
                           "path": f"autograd modules on HIP kernels ({a.precision} convolutions), train_be_gan.BEGanStep"},
                "losses": {k: round(float(v), 6) for k, v in out.items() if v.dim() == 0},
-               "roofline": {"bound": "hbm", "achieved": round(bytes_alg / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                            "frac": round(bytes_alg / dt / 8e12, 4), "traffic": None,
-                            "note": "whole-iteration algorithmic bytes / wall time: a launch-bound chain of ~1 000 small kernels "
-                                    "(rocprofv3 table: profiles/r03_*_be_gan_summary.md)"}}
+               "roofline": roof}
     if a.cpu_steps > 0:
         from oracle import ref_be as BE
         from oracle import ref_cpu as O

@@ -55,6 +55,10 @@ def main():
            "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3),
            "config": {"workload": f"aux_convs 256->32 + MaskNet + EdgeNet, {a.img}x{a.img} targets, batch {a.batch}",
                       "path": f"autograd modules on HIP kernels ({a.precision} convolutions)"}, "loss": float(loss)}
+    if True:      # per-entry-point roofline of the iteration (tools/op_roofline.py)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import op_roofline
+        out["roofline"] = op_roofline.roofline(op_roofline.trace(step, 2))
     if a.cpu_steps > 0:
         from oracle import ref_be as BE
         from oracle import ref_cpu as O

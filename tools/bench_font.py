@@ -113,6 +113,10 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
         return
+    if True:      # per-entry-point roofline of the iteration (tools/op_roofline.py)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import op_roofline
+        out["roofline"] = op_roofline.roofline(op_roofline.trace(iteration, 2))
     if a.cpu_steps > 0:
         from oracle import ref_cpu as O      # checker / CPU baseline only
         from oracle import ref_font as FN

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <vector>
 #include <string>
+#define VP_WGRAD5_Q 1
 #include "../../vae_play_amd/csrc/wgrad5.h"
 #include "../../vae_play_amd/csrc/split.h"
 

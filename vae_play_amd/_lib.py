@@ -58,11 +58,15 @@ SIGNATURES = {
     "vp_unpack_dw_im2col5_f32": (c_int, [P, P, c_int, c_int, P]),
     "vp_conv5_stats_workspace_bytes": (c_size_t, [c_int] * 7),
     "vp_conv5_gather_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_conv5_gather_stats_f32": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_conv5_scatter_stats_f32": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
+    "vp_conv5_stats_f32_workspace_bytes": (c_size_t, [c_int] * 7),
     "vp_conv5_scatter_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_split_fmt_f32": (c_int, [P, P, c_size_t, c_int, c_float, P]),
     "vp_nchw_to_nhwc_split_fmt_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_bn_act_fwd_split_fmt_f32": (c_int, [P] * 7 + [c_int, c_int, c_int, c_float, c_int, P]),
     "vp_bn_act_bwd_split_fmt_f32": (c_int, [P] * 10 + [c_int, c_int, c_int, c_float, c_int, c_int, c_float, P, c_size_t, P]),
+    "vp_bn_act_bwd_split_fmt_sat_f32": (c_int, [P] * 10 + [c_int, c_int, c_int, c_float, c_int, c_int, c_float, P, P, c_size_t, P]),
     "vp_im2col5s2_split_fmt_f32": (c_int, [P, P] + [c_int] * 6 + [P]),
     "vp_pack_w_im2col5_split_fmt": (c_int, [P, P, c_int, c_int, c_int, P]),
     "vp_conv5_gather_f16": (c_int, [P, P, P, P] + [c_int] * 8 + [c_float, P]),
@@ -175,7 +179,19 @@ def check(rc: int, what: str = "") -> None:
         raise VaePlayHipError(f"{what or 'vaeplay_hip'} failed (status {rc}): {msg.decode() if msg else ''}")
 
 
+TRACE = None     # benches only (tools/op_roofline.py): {"events": []} brackets every call with a HIP event pair on the launch stream
+
+
 def call(name: str, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
+    tr = TRACE
+    if tr is None:
+        check(getattr(load(), name)(*args), name)
+        return
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     rc = getattr(load(), name)(*args)
+    e1.record()
+    tr["events"].append((name, args, e0, e1))
     check(rc, name)

@@ -366,7 +366,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
                                                                const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
                                                                float* dx, u16_t* __restrict__ dx_split, int R, int C,
                                                                int rows_per_chunk, float invR, int act, float slope,
-                                                               size_t bxs = 0, int sfmt = SPLIT_BF16, float sscale = 1.f) {
+                                                               size_t bxs = 0, int sfmt = SPLIT_BF16, float sscale = 1.f,
+                                                               int* __restrict__ sat = nullptr) {
   x += blockIdx.z * bxs; dy += blockIdx.z * bxs; mean += blockIdx.z * (size_t)C; rstd += blockIdx.z * (size_t)C;
   sum_g += blockIdx.z * (size_t)C; sum_gx += blockIdx.z * (size_t)C;
   if (dx) dx += blockIdx.z * bxs;
@@ -394,6 +395,9 @@ __global__ void __launch_bounds__(256) bn_act_bwd_tiled_kernel(const float* __re
     }
     if (dx) *reinterpret_cast<vp_f32x4*>(dx + off) = o;
     if (dx_split) store_split4(dx_split, n, off, o[0] * sscale, o[1] * sscale, o[2] * sscale, o[3] * sscale, sfmt);
+    // fp16 pairs clamp at +-65504 (split.h): tell the caller that a scaled gradient left fp16's range (a sticky flag, any writer wins)
+    if (sat && sfmt == SPLIT_F16 &&
+        fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))) * sscale > 65504.f) *sat = 1;
   };
   int r = r0 + ty;
   for (; r + 3 * BN_TY < r1; r += 4 * BN_TY) {          // eight independent 16-B loads in flight
@@ -639,7 +643,7 @@ int vp_bn_act_fwd_split_fmt_f32(const float* x, const float* mean, const float* 
 static int bn_act_bwd_impl(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta, int R, int C, int act,
                            float slope, int batch_stats, void* ws, size_t ws_bytes, vp_stream stream, int fmt = SPLIT_BF16,
-                           float scale = 1.f) {
+                           float scale = 1.f, int* sat = nullptr) {
   VP_REQUIRE(x && dy && mean && rstd && (dx || dx_split) && ws && R > 0 && C > 0, "vp_bn_act_bwd_f32: bad arguments");
   VP_REQUIRE((fmt == SPLIT_BF16 || fmt == SPLIT_F16) && scale > 0.f, "vp_bn_act_bwd_split_fmt_f32: format 0 | 1, scale > 0");
   VP_REQUIRE(!dx_split || C % 4 == 0, "vp_bn_act_bwd_split_f32: C must be a multiple of 4");
@@ -663,7 +667,7 @@ static int bn_act_bwd_impl(const float* x, const float* dy, const float* mean, c
     BnGrid ga = bn_apply_grid(R, C);
     hipLaunchKernelGGL(bn_act_bwd_tiled_kernel, dim3(ga.chunks_r, ga.chunks_c), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
                        (const float*)sum_g, (const float*)sum_gx, dx, (u16_t*)dx_split, R, C, ga.rows_per_chunk, invR, act, slope,
-                       (size_t)0, fmt, scale);
+                       (size_t)0, fmt, scale, sat);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, x, dy, mean, rstd, gamma, beta,
                        (const float*)sum_g, (const float*)sum_gx, dx, n, C, invR, act, slope, (u16_t*)dx_split);
@@ -683,6 +687,14 @@ int vp_bn_act_bwd_split_fmt_f32(const float* x, const float* dy, const float* me
                                 float slope, int batch_stats, int fmt, float scale, void* ws, size_t ws_bytes, vp_stream stream) {
   return bn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, dx, dx_split, dgamma, dbeta, R, C, act, slope, batch_stats, ws, ws_bytes, stream,
                          fmt, scale);
+}
+
+int vp_bn_act_bwd_split_fmt_sat_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, float* dx, void* dx_split, float* dgamma, float* dbeta, int R, int C, int act,
+                                    float slope, int batch_stats, int fmt, float scale, int* saturated, void* ws, size_t ws_bytes,
+                                    vp_stream stream) {
+  return bn_act_bwd_impl(x, dy, mean, rstd, gamma, beta, dx, dx_split, dgamma, dbeta, R, C, act, slope, batch_stats, ws, ws_bytes, stream,
+                         fmt, scale, saturated);
 }
 
 int vp_bn_act_bwd_split_f32(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,

@@ -381,6 +381,14 @@ size_t vp_conv5_stats_workspace_bytes(int family, int B, int Hs, int Ws, int Cbi
 }
 
 }
+namespace vp {
+// the same finaliser for callers that do not see StatPlan (conv32.hip: the exact-f32 mode's statistics epilogue)
+int stats_slab_finish(const float* slab, int groups, int tiles_m, int bm, long M, long R, int N, float eps, float momentum, float* mean,
+                      float* rstd, float* rm, float* rv, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_stats_slab_final_kernel, dim3(N), dim3(256), 0, stream, slab, groups, tiles_m, bm, M, R, N, eps, momentum, mean, rstd, rm, rv);
+  return check_launch("vp_conv5_*_stats_f32(final)");
+}
+}  // namespace vp
 int vp16_stats_finish(const StatPlan& sp, const float* slab, float eps, float momentum, float* mean, float* rstd, float* rm, float* rv,
                         vp_stream stream) {
   hipLaunchKernelGGL(bn_stats_slab_final_kernel, dim3(sp.N), dim3(256), 0, (hipStream_t)stream, slab, sp.tiles_m * sp.gz, sp.tiles_m, sp.bm,

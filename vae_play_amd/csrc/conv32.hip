@@ -54,7 +54,19 @@ bool f32_fast_scatter_ok(const ConvGeom& g, const float* small, const float* w) 
          (size_t)g.B * g.Hs * g.Ws * g.Cs * 2 < ((size_t)1 << 31) && (size_t)g.Cb * 25 * g.Cs * 2 < ((size_t)1 << 31);
 }
 
-int f32_fast_gather(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g0, int act, hipStream_t s) {
+// split-K decisions, shared by the launchers and the statistics plan
+static int gather_ns32(long M, int N, int K2, int C2, bool has_bias, int act) {
+  // few output tiles and a long K (the 8x8-resolution layers): two K halves added atomically onto a zeroed output -- two addends,
+  // so the result does not depend on their order (bit-reproducible)
+  const long tiles = ((M + 127) / 128) * ((N + 63) / 64);
+  return (!has_bias && act == ACT_NONE && C2 % 64 == 0 && tiles < 384 && K2 >= 4096) ? 2 : 1;
+}
+static int scatter_ns32(long M, int N, int C2, int phases) {
+  const long tiles = ((M + 127) / 128) * ((N + 63) / 64) * phases;
+  return (C2 % 64 == 0 && tiles < 384 && 4 * C2 >= 1024) ? 2 : 1;
+}
+
+int f32_fast_gather(const float* big, const float* w_p0, const float* bias, float* out, const ConvGeom& g0, int act, hipStream_t s, float* stat) {
   typedef ProbF16T<true, 3> P;
   P p;
   p.alpha = 1.f;
@@ -66,10 +78,9 @@ int f32_fast_gather(const float* big, const float* w_p0, const float* bias, floa
   p.bias = bias; p.out = out; p.act = act;
   p.M = g0.B * g0.Hs * g0.Ws; p.N = g0.Cs; p.K = 25 * C2;
   const Tile16 t0 = tile32(p.M, p.N, 1);
-  // few output tiles and a long K (the 8x8-resolution layers): two K halves added atomically onto a zeroed output -- two addends,
-  // so the result does not depend on their order (bit-reproducible)
-  const long tiles = ((p.M + 127) / 128) * ((p.N + 63) / 64);
-  p.nsplit = (!bias && act == ACT_NONE && C2 % 64 == 0 && tiles < 384 && p.K >= 4096) ? 2 : 1;
+  p.nsplit = gather_ns32(p.M, p.N, p.K, C2, bias != nullptr, act);
+  p.stat = stat;
+  if (stat && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_gather_stats_f32: this shape splits K");
   p.k_per_split = p.nsplit == 2 ? ((p.K / 64 + 1) / 2) * 64 : p.K;
   if (p.nsplit == 2 && hipMemsetAsync(out, 0, (size_t)p.M * p.N * sizeof(float), s) != hipSuccess) return fail(VP_ERR_LAUNCH, "vp_conv_gather_f32: memset failed");
   const Tile16 t = p.nsplit == 2 ? tile32(p.M, p.N, 2) : t0;
@@ -79,7 +90,7 @@ int f32_fast_gather(const float* big, const float* w_p0, const float* bias, floa
   return check_launch("vp_conv_gather_f32(fast)");
 }
 
-int f32_fast_scatter(const float* small, const float* w_p1, float* out, const ConvGeom& g0, hipStream_t s) {
+int f32_fast_scatter(const float* small, const float* w_p1, float* out, const ConvGeom& g0, hipStream_t s, float* stat) {
   typedef ProbT16T<true, 3> P;
   P p;
   p.alpha = 1.f;
@@ -90,8 +101,9 @@ int f32_fast_scatter(const float* small, const float* w_p1, float* out, const Co
   p.w = (const u16*)w_p1; p.w_plane = 0;
   p.out = out; p.M = g0.B * g0.Hs * g0.Ws; p.N = g0.Cb;
   const int ph = g0.stride * g0.stride;
-  const long tiles = ((p.M + 127) / 128) * ((p.N + 63) / 64) * ph;
-  p.nsplit = (C2 % 64 == 0 && tiles < 384 && 4 * C2 >= 1024) ? 2 : 1;
+  p.nsplit = scatter_ns32(p.M, p.N, C2, ph);
+  p.stat = stat;
+  if (stat && p.nsplit != 1) return fail(VP_ERR_ARG, "vp_conv5_scatter_stats_f32: this shape splits K");
   if (p.nsplit == 2 && hipMemsetAsync(out, 0, (size_t)g0.B * g0.Hb * g0.Wb * g0.Cb * sizeof(float), s) != hipSuccess)
     return fail(VP_ERR_LAUNCH, "vp_conv_scatter_f32: memset failed");
   const int gz = ph * p.nsplit;
@@ -102,4 +114,67 @@ int f32_fast_scatter(const float* small, const float* w_p1, float* out, const Co
   return check_launch("vp_conv_scatter_f32(fast)");
 }
 
+
+// ---- BatchNorm statistics from the epilogue (as vp_conv5_*_stats_bf16x3): {pivot, sum(x - pivot), sum((x - pivot)^2)} per
+// (workgroup, channel) straight from the fp32 accumulators + one finaliser launch; removes bn_partial_kernel<0>'s read of the
+// activation for the layers that do not split K ---------------------------------------------------------------------------------
+struct Stat32 { int ok, bm, tiles_m, gz, N; long M, R; };
+
+static Stat32 stat_plan32(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
+  Stat32 sp = {0, 0, 0, 0, 0, 0, 0};
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || Cbig <= 0 || Csmall <= 0 || (stride != 1 && stride != 2) || !f32_fast_on()) return sp;
+  sp.M = (long)B * Hs * Ws;
+  if (family == 0) {
+    if (Cbig % 16 != 0 || Csmall < 64) return sp;
+    sp.N = Csmall;
+    if (gather_ns32(sp.M, sp.N, 25 * 2 * Cbig, 2 * Cbig, false, ACT_NONE) != 1) return sp;
+    sp.gz = 1; sp.R = sp.M;
+  } else {
+    if (Csmall % 16 != 0 || Cbig < 64) return sp;
+    sp.N = Cbig;
+    if (scatter_ns32(sp.M, sp.N, 2 * Csmall, stride * stride) != 1) return sp;
+    sp.gz = stride * stride; sp.R = sp.M * sp.gz;
+  }
+  sp.bm = tile32(sp.M, sp.N, sp.gz).bm;
+  sp.tiles_m = (int)((sp.M + sp.bm - 1) / sp.bm);
+  sp.ok = 1;
+  return sp;
+}
+
 }  // namespace vp
+
+using namespace vp;
+extern "C" {
+
+size_t vp_conv5_stats_f32_workspace_bytes(int family, int B, int Hs, int Ws, int Cbig, int Csmall, int stride) {
+  const Stat32 sp = stat_plan32(family, B, Hs, Ws, Cbig, Csmall, stride);
+  return sp.ok ? (size_t)3 * sp.N * sp.tiles_m * sp.gz * sizeof(float) : 0;
+}
+
+int vp_conv5_gather_stats_f32(const float* big, const float* w_p0, float* small_out, int B, int Hs, int Ws, int Cbig, int Csmall, int stride,
+                              float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var, void* ws,
+                              size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(big && w_p0 && small_out && mean && rstd && ws, "vp_conv5_gather_stats_f32: null pointer");
+  const Stat32 sp = stat_plan32(0, B, Hs, Ws, Cbig, Csmall, stride);
+  const ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, 5);
+  VP_REQUIRE(sp.ok && f32_fast_gather_ok(g, big, w_p0, VP_ACT_NONE), "vp_conv5_gather_stats_f32: this shape cannot emit statistics (vp_conv5_stats_f32_workspace_bytes() == 0)");
+  if (ws_bytes < (size_t)3 * sp.N * sp.tiles_m * sp.gz * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_gather_stats_f32: workspace too small");
+  int rc = f32_fast_gather(big, w_p0, nullptr, small_out, g, VP_ACT_NONE, (hipStream_t)stream, (float*)ws);
+  if (rc) return rc;
+  return stats_slab_finish((const float*)ws, sp.tiles_m * sp.gz, sp.tiles_m, sp.bm, sp.M, sp.R, sp.N, eps, momentum, mean, rstd, running_mean, running_var, (hipStream_t)stream);
+}
+
+int vp_conv5_scatter_stats_f32(const float* small, const float* w_p1, float* big_out, int B, int Hs, int Ws, int Csmall, int Cbig, int stride,
+                               float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var, void* ws,
+                               size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(small && w_p1 && big_out && mean && rstd && ws, "vp_conv5_scatter_stats_f32: null pointer");
+  const Stat32 sp = stat_plan32(1, B, Hs, Ws, Cbig, Csmall, stride);
+  const ConvGeom g = make_geom(B, Hs, Ws, Csmall, Cbig, stride, 5);
+  VP_REQUIRE(sp.ok && f32_fast_scatter_ok(g, small, w_p1), "vp_conv5_scatter_stats_f32: this shape cannot emit statistics (vp_conv5_stats_f32_workspace_bytes() == 0)");
+  if (ws_bytes < (size_t)3 * sp.N * sp.tiles_m * sp.gz * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_scatter_stats_f32: workspace too small");
+  int rc = f32_fast_scatter(small, w_p1, big_out, g, (hipStream_t)stream, (float*)ws);
+  if (rc) return rc;
+  return stats_slab_finish((const float*)ws, sp.tiles_m * sp.gz, sp.tiles_m, sp.bm, sp.M, sp.R, sp.N, eps, momentum, mean, rstd, running_mean, running_var, (hipStream_t)stream);
+}
+
+}

@@ -6,7 +6,7 @@
 namespace vp {
 
 // A/B knobs that the launchers consult per launch: a getenv() is a linear scan of the environment, so each knob is looked up ONCE
-// per process and call site -- unless VP_ENV_DYNAMIC=1, which the in-process A/B tools (tools/ab_env.py, ab_build.py, ab_multi.py,
+// per process and call site -- unless VP_ENV_DYNAMIC=1, which the in-process A/B tools (tools/ab_env.py, ab_build.py,
 // ab_multi.py) set before they load the library so that they can flip knobs between launches.
 struct EnvCache { bool set; char val[1024]; };
 inline EnvCache env_read(const char* name) {

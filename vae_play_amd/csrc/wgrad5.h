@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(512) wgrad5_kernel(const ProbW5 p) {
 }
 
 
+#if defined(VP_WGRAD5_Q)      // prototype, compiled by tools/kbench/wbench only (not dispatched: +2.5-4.5 % on two layers, slower on dec0)
 // ---- the same workgroup on v_mfma_f32_16x16x32_bf16 ("q" form, BN = 128 only) --------------------------------------------------
 // Equal FLOPs per cycle, but the chip holds a higher clock on this MFMA shape under load (MI355X_MICROARCH.md, DVFS give-back 7;
 // profiles/r02_notes.md section 1: +3-7 % on the gather / scatter kernels).  One MFMA covers the whole 32-pixel K-tile; the wave
@@ -434,6 +435,8 @@ __global__ void __launch_bounds__(512) wgrad5q_kernel(const ProbW5 p) {
   }
 }
 
+
+#endif  // VP_WGRAD5_Q
 
 // ---- exact fp32: the same workgroup on v_mfma_f32_32x32x2_f32 ---------------------------------------------------------------------
 // The exact-f32 plan's weight gradients ran igemm_kernel<ProbW> (one tap per workgroup, 45-55 % of the fp32-MFMA peak).  Same
@@ -673,8 +676,11 @@ inline void wgrad5_launch(const void* big_split, const void* small_split, float*
   p.dImg = g.dHW; p.dW = g.dW;
   p.alpha = alpha; p.dbg = dbg;
   const dim3 grid((unsigned)(8 * p.g8));
-  if (bn == 128 && m16) hipLaunchKernelGGL((wgrad5q_kernel<MODE>), grid, dim3(512), 0, stream, p);
-  else if (bn == 128) hipLaunchKernelGGL((wgrad5_kernel<128, MODE>), grid, dim3(512), 0, stream, p);
+#if defined(VP_WGRAD5_Q)
+  if (bn == 128 && m16) { hipLaunchKernelGGL((wgrad5q_kernel<MODE>), grid, dim3(512), 0, stream, p); *slab_splits = ns; return; }
+#endif
+  (void)m16;
+  if (bn == 128) hipLaunchKernelGGL((wgrad5_kernel<128, MODE>), grid, dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((wgrad5_kernel<64, MODE>), grid, dim3(512), 0, stream, p);
   *slab_splits = ns * (bn == 64 ? 2 : 1);
 }

@@ -245,6 +245,8 @@ class FusedVAEStep:
         # the next layer's HBM-bound BatchNorm backward.  The split output gradient they read is ping-ponged between
         # two buffers; before a buffer is rewritten the main stream waits for the weight gradient that read it.
         x2 = self.precision == "f16x2"                 # fp16-pair planes + the *_f16x2 launches (same plan structure)
+        # sticky device flag: a producer of fp16 gradient planes clamped a value (|g| * grad_scale16 > 65504); read in sync_counters()
+        self._f16_sat = torch.zeros(1, dtype=torch.int32, device=self.dev)
         x3 = self.precision in ("bf16x3", "f16x2")
         # (exact-f32 plans keep everything on the main stream: with their weight gradients on the side stream -- fp32 output gradients
         # rotating over two buffers, 128 / 160 / 192 CUs -- the step measured 8.39 / 8.06 / 8.03 ms against 7.89 ms in line,
@@ -308,7 +310,7 @@ class FusedVAEStep:
         def use16(cin, cout):
             return x3 and cin % 8 == 0 and cout % 8 == 0
 
-        fuse_stats = x3 and os.environ.get("VP_FUSE_BN_STATS", "1") != "0"
+        fuse_stats = os.environ.get("VP_FUSE_BN_STATS", "1") != "0"
         small_bn = True            # single-launch BatchNorm for <= 64 rows (-33 us per step, profiles/r02_notes.md section 2)
 
         def bn_block(tag, x_buf, R, Cn, bn_mod, y_buf, y_split=None, conv=None):
@@ -325,11 +327,11 @@ class FusedVAEStep:
             if conv is not None:
                 family, name, lead, geom, fl, ctag = conv
                 qgeom = geom if family == 0 else (geom[0], geom[1], geom[2], geom[4], geom[3], geom[5])   # query takes (Cbig, Csmall)
-                query = lib.vp_conv5_stats_f16_workspace_bytes if x2 else lib.vp_conv5_stats_workspace_bytes
+                query = (lib.vp_conv5_stats_f16_workspace_bytes if x2 else lib.vp_conv5_stats_workspace_bytes) if x3 else lib.vp_conv5_stats_f32_workspace_bytes
                 nst = query(family, *qgeom) if fuse_stats else 0
                 if nst:
                     st = self._ws(f"{tag}.statws", nst)
-                    fwd.add(name.replace("_bf16x3", "_stats_f16" if x2 else "_stats_bf16x3"), *lead, *geom, *(((FWD_PRODUCTS if family == 0 else DEC_FWD_PRODUCTS),) if x2 else ()),
+                    fwd.add(name.replace("_f32", "_stats_f32") if not x3 else name.replace("_bf16x3", "_stats_f16" if x2 else "_stats_bf16x3"), *lead, *geom, *(((FWD_PRODUCTS if family == 0 else DEC_FWD_PRODUCTS),) if x2 else ()),
                             eps_bn, mom, P(mean), P(rstd), P(bn_mod.running_mean), P(bn_mod.running_var), P(st), st.numel() * 4,
                             flops=fl, tag=ctag)
                     fused = True
@@ -359,9 +361,9 @@ class FusedVAEStep:
                         P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1)
                 return
             if x2 and dx_split is not None:      # gradient planes: fp16 pairs of GS * dx
-                bwd.add("vp_bn_act_bwd_split_fmt_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
+                bwd.add("vp_bn_act_bwd_split_fmt_sat_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
                         P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1, FMT, GS,
-                        P(ws), ws.numel() * 4)
+                        c_void_p(self._f16_sat.data_ptr()), P(ws), ws.numel() * 4)
                 return
             bwd.add("vp_bn_act_bwd_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
                     P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1,
@@ -417,8 +419,7 @@ class FusedVAEStep:
                 p0 = self._buf(f"enc{i}.p0", Cout * 25 * Cin)
                 p1 = self._buf(f"enc{i}.p1", Cin * 25 * Cout) if i > 0 else None
                 pack(blk.conv.weight, p0, p1, Cout, Cin, False, first=(i == 0))
-                fwd.add("vp_conv5_gather_f32", P(enc_in[-1]), P(p0), None, P(c), B, Hs, Hs, Cin, Cout, 2, _ACT_NONE,
-                        flops=fl, tag=f"enc{i}.fwd")
+                conv = (0, "vp_conv5_gather_f32", (P(enc_in[-1]), P(p0), P(c)), (B, Hs, Hs, Cin, Cout, 2), fl, f"enc{i}.fwd")
             # the activation feeds the next conv (+ its wgrad) or, for the last block, the flatten
             nxt16 = i + 1 < L and enc16[i + 1]
             a = None if nxt16 else self._buf(f"enc{i}.a", n_out)
@@ -482,8 +483,7 @@ class FusedVAEStep:
                 p1 = self._buf(f"dec{i}.p1", Cout * 25 * Cin)
                 p0 = self._buf(f"dec{i}.p0", Cin * 25 * Cout)
                 pack(blk.conv.weight, p0, p1, Cin, Cout, False)
-                fwd.add("vp_conv5_scatter_f32", P(dec_in[-1]), P(p1), P(tbuf), B, Hs, Hs, Cin, Cout, 2,
-                        flops=fl, tag=f"dec{i}.fwd")
+                conv = (1, "vp_conv5_scatter_f32", (P(dec_in[-1]), P(p1), P(tbuf)), (B, Hs, Hs, Cin, Cout, 2), fl, f"dec{i}.fwd")
             nxt16 = i + 1 < L and dec16[i + 1]
             # the last block feeds the final conv (fp32: its 3-channel side runs on the VALU kernels of narrow.hip;
             # measured: padding 3 -> 32 output columns for the MFMA halo kernel is LDS-read bound and 25 % slower)
@@ -625,9 +625,9 @@ class FusedVAEStep:
                         P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1)
                 return
             if x2 and dx_split is not None:      # gradient planes: fp16 pairs of GS * dx
-                bwd.add("vp_bn_act_bwd_split_fmt_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
+                bwd.add("vp_bn_act_bwd_split_fmt_sat_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
                         P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1, FMT, GS,
-                        P(ws), ws.numel() * 4)
+                        c_void_p(self._f16_sat.data_ptr()), P(ws), ws.numel() * 4)
                 return
             bwd.add("vp_bn_act_bwd_split_f32", P(x_buf), P(dy_buf), P(mean), P(rstd), P(bn_mod.weight), P(bn_mod.bias),
                     P(dx_buf), P(dx_split), P(grad_of(bn_mod.weight)), P(grad_of(bn_mod.bias)), R, Cn, _ACT_RELU, 0.0, 1,
@@ -813,12 +813,19 @@ class FusedVAEStep:
         return n
 
     def sync_counters(self):
-        """Advance BatchNorm ``num_batches_tracked`` buffers (bookkeeping only; kept off the hot path)."""
+        """Advance BatchNorm ``num_batches_tracked`` buffers (bookkeeping only; kept off the hot path).  precision="f16x2": also reads
+        the sticky saturation flag of the fp16 gradient planes (a host sync, like everything here) and raises when a step since the
+        last call clamped a gradient at +-65504 / grad_scale16 -- the weights of those steps are off; lower ``grad_scale16``."""
         n = getattr(self, "_steps_since_sync", 0)
         if n:
             for m in self._bn_mods:
                 m.num_batches_tracked.add_(n)
             self._steps_since_sync = 0
+        if self.precision == "f16x2" and int(self._f16_sat.item()):
+            self._f16_sat.zero_()
+            raise _lib.VaePlayHipError(
+                f"precision='f16x2': gradient planes saturated fp16's range since the last sync_counters() (|g| * grad_scale16 > 65504 "
+                f"with grad_scale16 = {self.grad_scale16:g}); build the step with a smaller power of two")
 
     def _decoder_slice_start(self) -> int:
         """Arena offset of the first decoder parameter (encoder parameters precede it in ``vae.parameters()``)."""
