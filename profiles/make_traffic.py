@@ -22,16 +22,21 @@ def load(path):
 
 
 F, W = load(fa), load(fb)
-fam = {"vp_conv5_gather_bf16x3": "ProbF16", "vp_conv5_scatter_bf16x3": "ProbT16", "vp_conv5_wgrad_bf16x3": "ProbW16"}
+# kernels behind each entry point: the register-staged igemm16_kernel, the pipelined igemm16p_kernel (PF16 / PT16) and, for the weight
+# gradient, the rows-of-taps wgrad5_kernel (round 3)
+fam = {"vp_conv5_gather_bf16x3": ("ProbF16", "PF16"), "vp_conv5_scatter_bf16x3": ("ProbT16", "PT16"),
+       "vp_conv5_wgrad_bf16x3": ("ProbW16", "wgrad5_kernel")}
 res = {"_provenance": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, serial schedule VP_SIDE_WGRAD=0) of "
        "`python bench.py --steps 2 --warmup 1 --no-settle --no-cpu-baseline` on one MI355X; bytes = 2*FETCH_SIZE*1024 (gfx950 reports "
-       "half of wide streaming reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024, averaged over the launches of the igemm16 "
-       "kernels of each family (for the weight gradient: main kernel; its slab reduction is listed separately in the .md); "
+       "half of wide streaming reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024, averaged over the launches of the igemm16 / "
+       "igemm16p / wgrad5 kernels of each family (for the weight gradient: main kernel; its slab reduction is listed separately in the "
+       ".md); "
        "FETCH_SIZE counts fabric requests (Infinity-Cache hits included).", "unit": "bytes per launch"}
-for ep, tag in fam.items():
-    f = sum(v[0] for k, v in F.items() if tag in k and "igemm16_kernel" in k)
-    n = sum(v[1] for k, v in F.items() if tag in k and "igemm16_kernel" in k)
-    w = sum(v[0] for k, v in W.items() if tag in k and "igemm16_kernel" in k)
+for ep, tags in fam.items():
+    hit = lambda k: any(t in k for t in tags) and ("igemm16" in k or "wgrad5" in k)
+    f = sum(v[0] for k, v in F.items() if hit(k))
+    n = sum(v[1] for k, v in F.items() if hit(k))
+    w = sum(v[0] for k, v in W.items() if hit(k))
     res[ep] = int((2 * f + w) * 1024 / max(n, 1))
 tf, tw = sum(v[0] for v in F.values()), sum(v[0] for v in W.values())
 res["whole_step_bytes"] = {"fetch_x2": int(2 * tf * 1024 / steps), "write": int(tw * 1024 / steps)}

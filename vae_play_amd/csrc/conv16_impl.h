@@ -135,6 +135,11 @@ static int scatter16_t(const void* small_split, const void* w_p1_split, float* b
     }
   }
   p.xcd_map = xcd_map_for(p.M, p.N, stride * stride * p.nsplit, Csmall);
+  {
+    const Tile16 t = choose_tile16(p.M, p.N, stride * stride * p.nsplit, false, Csmall);
+    const long wgs = ((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn) * stride * stride * p.nsplit;
+    p.pair_phases = (stride == 2 && p.nsplit == 1 && wgs <= 512) ? 1 : 0;
+  }
   launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
   return check_launch("vp_conv_scatter_bf16x3");
 }

@@ -109,6 +109,7 @@ int f32_fast_scatter(const float* small, const float* w_p1, float* out, const Co
   const int gz = ph * p.nsplit;
   const Tile16 t = tile32(p.M, p.N, gz);
   p.xcd_map = xcd32(p.M, p.N, t);
+  p.pair_phases = (g0.stride == 2 && p.nsplit == 1 && ((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn) * gz <= 512) ? 1 : 0;
   if (C2 % 64 == 0) launch32_bk<P, 64>(p, p.M, p.N, gz, s, t);
   else launch32_bk<P, 32>(p, p.M, p.N, gz, s, t);
   return check_launch("vp_conv_scatter_f32(fast)");

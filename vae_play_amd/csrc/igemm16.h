@@ -195,6 +195,7 @@ struct ProbT16T {
   float* out; const void* zero; ConvGeom g; int M, N;
   int nsplit;                // 1, or 2: z = phase*2 + half, halves atomically added onto a zeroed output
   int xcd_map;
+  int pair_phases = 0;       // see z_setup
   static constexpr bool HAS_STAT = true;
   float* stat = nullptr;     // see ProbF16T
   struct ZCtx { int k_begin, k_end, ph, pw, th, tw, r0h, r0w, bh, bw; };   // phase geometry as in problems.h ProbT
@@ -209,7 +210,13 @@ struct ProbT16T {
   struct ARow { int pix_base, q, p, valid; };
   struct BRow { int off, valid; };
   VP_HD void z_setup(int zi, ZCtx& z) const {
-    const int phase = zi / nsplit, half = zi - phase * nsplit;
+    int phase = zi / nsplit;
+    const int half = zi - phase * nsplit;
+    // stride 2: the four phases contract 9 / 6 / 6 / 4 taps.  Workgroups are dealt to the CUs round-robin in z-major order, so when a
+    // launch is at most two workgroups per CU (`pair_phases`, set by the host: dec1.fwd at 32 images has 512) CU c runs z = 0 beside
+    // z = 2 and z = 1 beside z = 3: issuing the 4-tap phase third pairs 9 + 4 and 6 + 6 instead of 9 + 6 and 6 + 4 (dec1.fwd 187 ->
+    // 180 us, 522 -> 472 us in fp32).  Launches of several rounds keep longest-first (there the swap costs 3 - 20 %).
+    if (pair_phases && g.stride == 2 && phase >= 2) phase = 5 - phase;
     int s = g.stride; z.ph = phase / s; z.pw = phase - z.ph * s;
     z.r0h = (z.ph + pad()) % s; z.r0w = (z.pw + pad()) % s;
     z.th = z.r0h < ks() ? (ks() - z.r0h + s - 1) / s : 0; z.tw = z.r0w < ks() ? (ks() - z.r0w + s - 1) / s : 0;
