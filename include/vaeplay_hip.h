@@ -159,6 +159,9 @@ int vp_conv5_scatter_stats_bf16x3(const void* small_split, const void* w_p1_spli
  * layout, split-bf16 arithmetic on the matrix cores with one kernel row of taps (5*C contiguous floats of `small`) per MFMA k-step. */
 int vp_conv5_smallin_dgrad_bf16x3(const float* small, const float* w_ref, float* big_out, int B, int H, int W, int Csmall, int Cbig,
                                   vp_stream stream);
+/* The same input gradient (models/networks.py:100-103 backward) in exact fp32: v_mfma_f32_32x32x2_f32 on the same rows-in-K tiling. */
+int vp_conv5_smallin_dgrad_f32(const float* small, const float* w_ref, float* big_out, int B, int H, int W, int Csmall, int Cbig,
+                               vp_stream stream);
 /* Forward pass of a stride-1 first conv on a 1- or 3-channel image (nn.Conv2d(C, 32 | 64, k5, s1, p2) + ReLU, the VAE-GAN
  * discriminator's first layer, models/networks.py:160-163): big_out[b,h,w,cf] = act(bias[cf] + sum small[b,h+r-2,w+q-2,n] * w_ref[cf][n][r][q]),
  * fp32 NHWC operands, reference weight layout, act none | relu; the same rows-in-K kernel as vp_conv5_smallin_dgrad_bf16x3. */

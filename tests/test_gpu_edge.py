@@ -83,6 +83,11 @@ def test_final_conv_input_gradient_rowk_matches_torch(B, H, W, nin):
     # the exact-fp32 scatter kernel computes the same gradient
     _, p1 = ops.pack_w5(w.cuda(), False, True)
     assert_close(out.cpu(), ops.conv5_scatter(dld, p1, 1).cpu(), 3e-5, "rows-in-K vs exact-f32 kernel")
+    # ... and so does the exact-fp32 form of the rows-in-K kernel (v_mfma_f32_32x32x2_f32, k permuted inside a kernel row)
+    out32 = torch.full((B, 64, H, W), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
+    _lib.call("vp_conv5_smallin_dgrad_f32", ops._p(dld), ops._p(w.cuda()), ops._p(out32), B, H, W, nin, 64, ops._stream())
+    assert torch.isfinite(out32).all(), "every output element must be written"
+    assert_close(out32.cpu(), ref, 2e-6, f"final conv input gradient rows-in-K exact f32 {B}x{H}x{W}x{nin}")
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 1, 32), (1, 24, 40, 3, 32), (2, 33, 17, 1, 64), (3, 128, 128, 1, 32)])

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vp_conv5_scatter_stats_f16": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_conv5_smallin_fwd_bf16x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_smallin_dgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_conv5_smallin_dgrad_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_conv5_wgrad_bf16x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "vp_conv5_wgrad_bf16x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "vp_conv5_wgrad_bf16x3_cus": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

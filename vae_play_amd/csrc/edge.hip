@@ -301,6 +301,100 @@ __global__ void __launch_bounds__(512, 2) dgrad_rowk_kernel(const float* __restr
   }
 }
 
+// Exact-fp32 form of the input gradient above (round 3): the same patch, tile list and output mapping on v_mfma_f32_32x32x2_f32.  The
+// k = 16 of a kernel row is permuted so that a lane keeps the bf16 kernel's loads: lane half lh holds k = 8*lh + j (j = 0..7) and MFMA
+// step j contracts k in {j, 8 + j}; the weight fragments are parked in LDS in that order, as [row][column tile][j / 4][lane][j % 4] so that
+// a lane reads them with two conflict-free 16-byte loads.  40 k-steps x CF/32 column tiles = 80 MFMAs of 64 cycles per 32 pixels x 64
+// channels: 34 us of matrix time at B = 32, 128 x 128 (the layer's floor, writing its 134-MB result, is 27 us).
+template <int NIN, int CF>
+__global__ void __launch_bounds__(512, 2) dgrad_rowk_f32_kernel(const float* __restrict__ dlogit, const float* __restrict__ w,
+                                                                float* __restrict__ out, int H, int W, int tiles_x, int tiles_per_img,
+                                                                int ntiles) {
+  static_assert(CF == 64 || CF == 32, "wide channel count");
+  constexpr int NJT = CF / 32;
+  constexpr int TR = 8, TC = 32, PR = TR + 4, PC = (TC + 4) * NIN + 8;
+  constexpr int KROW = 5 * NIN;
+  __shared__ float patch[PR * PC];
+  typedef float f32x4_l __attribute__((ext_vector_type(4)));
+  typedef float f32x16_l __attribute__((ext_vector_type(16)));
+  __shared__ __attribute__((aligned(16))) f32x4_l bfr[5 * NJT * 2 * 64];                 // weight fragments [r][jt][j / 4][lane] x (j % 4)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  if (wave < 5) {
+    const int r = wave;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+        f32x4_l x;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int k = 8 * lh + 4 * jh + jj, d = k / NIN, n = k - d * NIN, cf = 32 * jt + li;
+          x[jj] = k < KROW ? w[(((size_t)n * CF + cf) * 5 + r) * 5 + (4 - d)] : 0.f;
+        }
+        bfr[((r * NJT + jt) * 2 + jh) * 64 + lane] = x;
+      }
+  }
+  constexpr int NPE = PR * (TC + 4) * NIN, NPV = (NPE + 511) / 512;
+  float pv[NPV];
+  auto load_patch = [&](int tile) {
+    const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+    const int h0 = (rem / tiles_x) * TR, w0 = (rem % tiles_x) * TC;
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) {
+      const int i = tid + 512 * u;
+      const int pr = i / ((TC + 4) * NIN), e = i - pr * ((TC + 4) * NIN);
+      const int px = e / NIN, n = e - px * NIN;
+      const int h = h0 - 2 + pr, ww = w0 - 2 + px;
+      pv[u] = (i < NPE && h >= 0 && h < H && ww >= 0 && ww < W) ? dlogit[((size_t)(b * H + h) * W + ww) * NIN + n] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_patch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+    const int h0 = (rem / tiles_x) * TR, w0 = (rem % tiles_x) * TC;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) {
+      const int i = tid + 512 * u;
+      if (i < NPE) { const int pr = i / ((TC + 4) * NIN); patch[pr * PC + (i - pr * ((TC + 4) * NIN))] = pv[u]; }
+    }
+    if (tid < PR * 8) patch[(tid >> 3) * PC + (TC + 4) * NIN + (tid & 7)] = 0.f;
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_patch(tile + (int)gridDim.x);
+    f32x16_l acc[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[jt][e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const float* q = &patch[(wave + 4 - r) * PC + li * NIN + 8 * lh];
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = (8 * lh + j < KROW) ? q[j] : 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NJT; ++jt) {
+        const f32x4_l b0 = bfr[((r * NJT + jt) * 2 + 0) * 64 + lane], b1 = bfr[((r * NJT + jt) * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], b0[j], acc[jt], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[4 + j], b1[j], acc[jt], 0, 0, 0);
+      }
+    }
+    const int h = h0 + wave;
+    if (h < H) {
+#pragma unroll
+      for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ww = w0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (ww < W) out[((size_t)(b * H + h) * W + ww) * CF + 32 * jt + li] = acc[jt][e];
+        }
+    }
+  }
+}
+
 bool rowk_dgrad_applicable(int B, int H, int W, int Cbig, int Csmall) {
   const bool on = true;
   return on && B > 0 && H > 0 && W > 0 && Cbig == 64 && (Csmall == 1 || Csmall == 3);
@@ -340,6 +434,21 @@ int vp_conv5_smallin_dgrad_bf16x3(const float* small, const float* w_ref, float*
     hipLaunchKernelGGL((dgrad_rowk_kernel<1, 64, false>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
                        tiles_x * tiles_y, ntiles, (const float*)nullptr, 0);
   return check_launch("vp_conv5_smallin_dgrad_bf16x3");
+}
+
+int vp_conv5_smallin_dgrad_f32(const float* small, const float* w_ref, float* big_out, int B, int H, int W, int Csmall, int Cbig,
+                               vp_stream stream) {
+  VP_REQUIRE(small && w_ref && big_out, "vp_conv5_smallin_dgrad_f32: null pointer");
+  VP_REQUIRE(rowk_dgrad_applicable(B, H, W, Cbig, Csmall), "vp_conv5_smallin_dgrad_f32: needs 64 big channels and 1 or 3 small channels");
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8, ntiles = B * tiles_x * tiles_y;
+  const int grid = ntiles < 512 ? ntiles : 512;
+  if (Csmall == 3)
+    hipLaunchKernelGGL((dgrad_rowk_f32_kernel<3, 64>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
+                       tiles_x * tiles_y, ntiles);
+  else
+    hipLaunchKernelGGL((dgrad_rowk_f32_kernel<1, 64>), dim3(grid), dim3(512), 0, (hipStream_t)stream, small, w_ref, big_out, H, W, tiles_x,
+                       tiles_x * tiles_y, ntiles);
+  return check_launch("vp_conv5_smallin_dgrad_f32");
 }
 
 int vp_conv5_smallin_fwd_bf16x3(const float* small, const float* w_ref, const float* bias, float* big_out, int B, int H, int W, int Csmall,

@@ -249,8 +249,10 @@ class FusedVAEStep:
         self._f16_sat = torch.zeros(1, dtype=torch.int32, device=self.dev)
         x3 = self.precision in ("bf16x3", "f16x2")
         # (exact-f32 plans keep everything on the main stream: with their weight gradients on the side stream -- fp32 output gradients
-        # rotating over two buffers, 128 / 160 / 192 CUs -- the step measured 8.39 / 8.06 / 8.03 ms against 7.89 ms in line,
-        # profiles/r03_notes.md: every fp32-MFMA kernel is compute-bound, there is no HBM-bound partner worth the contention)
+        # rotating over two buffers, 128 / 160 / 192 CUs -- the step measured 8.39 / 8.06 / 8.03 ms against 7.89 ms in line; with only
+        # the bandwidth-bound glue there -- slab reductions, final conv's VALU weight gradient, weight re-pack, early Adam slices, one
+        # category at a time -- 7.72 - 7.79 ms against 7.66 in line: beside an fp32-MFMA kernel ANY second kernel costs more than it
+        # hides, profiles/r03_notes.md sections 2 and 8)
         side_on = x3
         FMT = 1 if x2 else 0                           # VP_SPLIT_F16 | VP_SPLIT_BF16
         GS = self.grad_scale16 if x2 else 1.0          # scale of gradient planes; 1/GS in the launches that consume them
@@ -555,6 +557,8 @@ class FusedVAEStep:
             bwd.add("vp_conv5_smallin_dgrad_bf16x3", P(dlogit), P(fin.weight), P(gA), B, S, S, C, Cf, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         elif fin16:
             bwd.add("vp_conv5_scatter_bf16x3", P(dlogit_s), P(fp1s), P(gA), B, S, S, 8, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
+        elif Cf == 64 and C in (1, 3):    # exact fp32 on the same rows-in-K tiling (csrc/edge.hip dgrad_rowk_f32_kernel)
+            bwd.add("vp_conv5_smallin_dgrad_f32", P(dlogit), P(fin.weight), P(gA), B, S, S, C, Cf, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         else:
             bwd.add("vp_conv5_scatter_f32", P(dlogit), P(fp1), P(gA), B, S, S, C, Cf, 1, flops=50.0 * B * S * S * Cf * C, tag="fin.dgrad")
         cur, other = gA, gB
