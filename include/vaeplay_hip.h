@@ -130,6 +130,11 @@ int vp_conv5_smallout_bf16x3(const float* big, const float* w_p0, const float* b
 size_t vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(int B, int H, int W, int Cbig, int Csmall);
 int vp_conv5_smallout_wgrad_bf16x3(const float* big, const float* small, float* dw_ref, int B, int H, int W, int Cbig, int Csmall,
                                    void* ws, size_t ws_bytes, vp_stream stream);
+/* The same weight gradient in exact fp32 (v_mfma_f32_32x32x2_f32, the dlogit patch and u as fp32 in LDS, the pixels of a super-step
+ * split over the four waves and their partial sums added in a fixed order): same workspace size, same slab layout and reduction. */
+size_t vp_conv5_smallout_wgrad_f32_workspace_bytes(int B, int H, int W, int Cbig, int Csmall);
+int vp_conv5_smallout_wgrad_f32(const float* big, const float* small, float* dw_ref, int B, int H, int W, int Cbig, int Csmall,
+                                void* ws, size_t ws_bytes, vp_stream stream);
 /* First encoder conv (nn.Conv2d(C, 64, k5, s2, p2, bias=False) with C = 1 or 3 image channels, models/networks.py:14 via :55):
  * its im2col is materialised once per step as split planes [B*Hs*Ws][KC] (KC = vp_im2col5s2_cols(C): 96 / 64), after which the
  * forward convolution is vp_conv_gather_bf16x3(ks = 1, Cbig = KC) and the weight gradient vp_conv_wgrad_bf16x3(ks = 1) on the

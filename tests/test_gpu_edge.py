@@ -60,6 +60,13 @@ def test_final_conv_weight_gradient_tapm_matches_torch(B, H, W, nout):
     dw2 = torch.empty_like(dw)
     _lib.call("vp_conv5_smallout_wgrad_bf16x3", ops._p(ud), ops._p(dld), ops._p(dw2), B, H, W, 64, nout, ops._p(ws), nbytes, ops._stream())
     assert torch.equal(dw, dw2), "slab reduction must be bit-reproducible"
+    # the exact-fp32 form of the same scheme (v_mfma_f32_32x32x2_f32, pixels split over the four waves, fixed-order sum through LDS)
+    assert lib.vp_conv5_smallout_wgrad_f32_workspace_bytes(B, H, W, 64, nout) == nbytes
+    dw3, dw4 = torch.full_like(dw, float("nan")), torch.empty_like(dw)
+    _lib.call("vp_conv5_smallout_wgrad_f32", ops._p(ud), ops._p(dld), ops._p(dw3), B, H, W, 64, nout, ops._p(ws), nbytes, ops._stream())
+    assert_close(dw3.cpu(), ref, 3e-6, f"final conv wgrad taps-in-M exact f32 {B}x{H}x{W}x{nout}")
+    _lib.call("vp_conv5_smallout_wgrad_f32", ops._p(ud), ops._p(dld), ops._p(dw4), B, H, W, 64, nout, ops._p(ws), nbytes, ops._stream())
+    assert torch.equal(dw3, dw4), "exact-f32 taps-in-M: bit-reproducible"
 
 
 @pytest.mark.parametrize("B,H,W,nin", [(2, 16, 32, 3), (1, 24, 40, 3), (3, 33, 17, 1), (2, 128, 128, 3), (1, 256, 256, 1)])

@@ -52,6 +52,8 @@ SIGNATURES = {
     "vp_conv5_smallout_bf16x3": (c_int, [P, P, P, P] + [c_int] * 6 + [P]),
     "vp_conv5_smallout_wgrad_bf16x3_workspace_bytes": (c_size_t, [c_int] * 5),
     "vp_conv5_smallout_wgrad_bf16x3": (c_int, [P, P, P] + [c_int] * 5 + [P, c_size_t, P]),
+    "vp_conv5_smallout_wgrad_f32_workspace_bytes": (c_size_t, [c_int] * 5),
+    "vp_conv5_smallout_wgrad_f32": (c_int, [P, P, P] + [c_int] * 5 + [P, c_size_t, P]),
     "vp_im2col5s2_cols": (c_int, [c_int]),
     "vp_im2col5s2_split_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_pack_w_im2col5_split": (c_int, [P, P, c_int, c_int, P]),

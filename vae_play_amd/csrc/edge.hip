@@ -140,6 +140,141 @@ __global__ void __launch_bounds__(256, 2) wgrad_tapm_kernel(const float* __restr
   }
 }
 
+// Exact-fp32 form of the taps-in-M weight gradient (round 3): the same band / patch / slab scheme on v_mfma_f32_32x32x2_f32.
+//   * the dlogit patch sits in LDS as fp32; an A element of row (tap, n) and pixel p is ONE ds_read_b32 at the lane's tap shift;
+//   * u streams through LDS 64 pixels at a time as fp32, [pixel][channel] with a 96-float pitch: an MFMA step contracts the pixel pair
+//     (2j, 2j + 1), lane half lh takes pixel 2j + lh, and the two halves of a B read fall into disjoint bank halves;
+//   * all four waves compute: each owns 16 of a super-step's 64 pixels and ALL 3 x 2 accumulator blocks (96 registers) -- the K split
+//     keeps the four SIMDs equally loaded where "one 32-row block per wave" leaves one idle -- and the four partial sums are added in
+//     a fixed order through LDS before the slab is written (bit-reproducible);
+//   * 48 MFMAs of 64 cycles per wave and super-step: 41 us of matrix time at B = 32, 128 x 128 (the VALU kernel took 151 us).
+template <int NOUT, int TH>
+__global__ void __launch_bounds__(256, 2) wgrad_tapm_f32_kernel(const float* __restrict__ u, const float* __restrict__ dlogit,
+                                                                float* __restrict__ slab, int H, int W, int bands_per_img) {
+  constexpr int C = 64, NCOL = 25 * NOUT, MT = (NCOL + 31) / 32;
+  constexpr int SS = 64, UP = 96;                          // pixels per super-step, u row pitch (floats)
+  constexpr int UBUF = SS * UP;                            // floats per u buffer
+  static_assert(MT <= 3, "row blocks");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const ubuf = reinterpret_cast<float*>(smem);
+  float* const patch = ubuf + 2 * UBUF;
+  const int PC = ((W + 4 + 7) / 8) * 8;
+  const int PLANE_E = (TH + 4) * PC;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / bands_per_img, h0 = (blockIdx.x - b * bands_per_img) * TH;
+
+  for (int i = tid; i < NOUT * PLANE_E; i += 256) {
+    const int n = i / PLANE_E, rem = i - n * PLANE_E;
+    const int pr = rem / PC, pc = rem - pr * PC;
+    const int h = h0 - 2 + pr, w = pc - 2;
+    patch[i] = (h >= 0 && h < H && w >= 0 && w < W) ? dlogit[((size_t)(b * H + h) * W + w) * NOUT + n] : 0.f;
+  }
+
+  // per-lane constants: rows m = 32*rb + li -> (tap, n) -> element offset of the tap shift (+ this wave's pixel quarter + lane half)
+  int a_off[MT];
+  bool mrow[MT];
+#pragma unroll
+  for (int rb = 0; rb < MT; ++rb) {
+    const int m = 32 * rb + li;
+    mrow[rb] = m < NCOL;
+    const int tap = mrow[rb] ? m / NOUT : 0, n_ = mrow[rb] ? m - tap * NOUT : 0;
+    const int r_ = tap / 5, q_ = tap - 5 * r_;
+    a_off[rb] = n_ * PLANE_E + (4 - r_) * PC + (4 - q_) + 16 * wave + lh;
+  }
+
+  const int spx = tid >> 2, sch = (tid & 3) * 16;
+  vp_f32x4 st[4];
+  const int nss = TH * W / SS;
+  auto load_ss = [&](int ss) {
+    const int p0 = ss * SS + spx;
+    const int hr = p0 / W, w = p0 - hr * W;
+    const float* src = u + ((size_t)(b * H + h0 + hr) * W + w) * C + sch;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) st[v] = ld4(src + 4 * v);
+  };
+  auto write_ss = [&](int buf) {
+    float* base = ubuf + buf * UBUF + spx * UP + sch;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) *reinterpret_cast<vp_f32x4*>(base + 4 * v) = st[v];
+  };
+
+  f32x16_t acc[MT][2];
+#pragma unroll
+  for (int rb = 0; rb < MT; ++rb)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][j][r] = 0.f;
+
+  load_ss(0);
+  write_ss(0);
+  __syncthreads();
+  for (int ss = 0; ss < nss; ++ss) {
+    const bool more = ss + 1 < nss;
+    if (more) load_ss(ss + 1);
+    {
+      const float* ub = ubuf + (ss & 1) * UBUF + (16 * wave + lh) * UP + li;
+      const int pbase = ss * SS;
+      const int hr = pbase / W, w0 = pbase - hr * W;
+      const float* pa = patch + hr * PC + w0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float b0 = ub[2 * j * UP], b1 = ub[2 * j * UP + 32];
+#pragma unroll
+        for (int rb = 0; rb < MT; ++rb) {
+          float a = pa[a_off[rb] + 2 * j];
+          a = mrow[rb] ? a : 0.f;
+          acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[rb][0], 0, 0, 0);
+          acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[rb][1], 0, 0, 0);
+        }
+      }
+    }
+    if (more) write_ss((ss + 1) & 1);
+    __syncthreads();
+  }
+  // the four waves' partial sums, added in a fixed order through the (now free) u buffers: (0 += 2, 1 += 3), then 0 += 1
+  constexpr int WREGS = MT * 2 * 16;
+  float* const red = ubuf;                                  // 2 x WREGS x 64 floats <= 2 * UBUF
+  static_assert(2 * WREGS * 64 <= 2 * UBUF, "reduction scratch");
+  auto park = [&](int slot) {
+#pragma unroll
+    for (int rb = 0; rb < MT; ++rb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((slot * WREGS) + (rb * 2 + j) * 16 + r) * 64 + lane] = acc[rb][j][r];
+  };
+  auto take = [&](int slot) {
+#pragma unroll
+    for (int rb = 0; rb < MT; ++rb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][j][r] += red[((slot * WREGS) + (rb * 2 + j) * 16 + r) * 64 + lane];
+  };
+  if (wave >= 2) park(wave - 2);
+  __syncthreads();
+  if (wave < 2) take(wave);
+  __syncthreads();
+  if (wave == 1) park(0);
+  __syncthreads();
+  if (wave == 0) {
+    take(0);
+    float* out = slab + (size_t)blockIdx.x * NCOL * C;
+#pragma unroll
+    for (int rb = 0; rb < MT; ++rb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < NCOL) out[(size_t)row * C + 32 * j + li] = acc[rb][j][r];
+        }
+  }
+}
+
 constexpr int TAPM_TH = 8;        // band height: 8 rows = two workgroups per CU (16 rows, one per CU, left too few loads in flight: 57 us)
 
 bool tapm_wgrad_applicable(const ConvGeom& g) {
@@ -172,6 +307,29 @@ int tapm_wgrad_launch(const float* big_f32, const float* small_f32, float* dw_re
   int rc = check_launch("wgrad_tapm");
   if (rc) return rc;
   return slab_reduce_launch(ws, dw_ref, g.Cs, g.Cb, nblk, s, kTaps);      // few outputs, many slabs: the deep reduction kernel
+}
+
+static size_t tapm_f32_lds_bytes(const ConvGeom& g) {
+  const int PC = ((g.Ws + 4 + 7) / 8) * 8;
+  return (size_t)2 * 64 * 96 * 4 + (size_t)g.Cs * (TAPM_TH + 4) * PC * 4;
+}
+
+int tapm_wgrad_f32_launch(const float* big_f32, const float* small_f32, float* dw_ref, const ConvGeom& g, float* ws, hipStream_t s) {
+  const int bands = g.Hs / TAPM_TH, nblk = g.B * bands;
+  const size_t lds = tapm_f32_lds_bytes(g);
+  if (lds > 160 * 1024) return fail(VP_ERR_ARG, "wgrad_tapm_f32: image too wide for the LDS patch");
+  if (g.Cs == 3) {
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute((const void*)wgrad_tapm_f32_kernel<3, TAPM_TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
+    hipLaunchKernelGGL((wgrad_tapm_f32_kernel<3, TAPM_TH>), dim3(nblk), dim3(256), lds, s, big_f32, small_f32, ws, g.Hs, g.Ws, bands);
+  } else {
+    static bool attr1 = false;
+    if (!attr1) { (void)hipFuncSetAttribute((const void*)wgrad_tapm_f32_kernel<1, TAPM_TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    hipLaunchKernelGGL((wgrad_tapm_f32_kernel<1, TAPM_TH>), dim3(nblk), dim3(256), lds, s, big_f32, small_f32, ws, g.Hs, g.Ws, bands);
+  }
+  int rc = check_launch("wgrad_tapm_f32");
+  if (rc) return rc;
+  return slab_reduce_launch(ws, dw_ref, g.Cs, g.Cb, nblk, s, kTaps);
 }
 
 
@@ -419,6 +577,20 @@ int vp_conv5_smallout_wgrad_bf16x3(const float* big, const float* small, float* 
   VP_REQUIRE(tapm_wgrad_applicable(g), "vp_conv5_smallout_wgrad_bf16x3: needs 64 input channels, 1 or 3 outputs, width a multiple of 64, height of 8");
   if (ws_bytes < tapm_wgrad_ws_floats(g) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_smallout_wgrad_bf16x3: workspace too small");
   return tapm_wgrad_launch(big, small, dw_ref, g, (float*)ws, (hipStream_t)stream);
+}
+
+size_t vp_conv5_smallout_wgrad_f32_workspace_bytes(int B, int H, int W, int Cbig, int Csmall) {
+  return vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(B, H, W, Cbig, Csmall);       // (the same bands, the same slabs)
+}
+
+int vp_conv5_smallout_wgrad_f32(const float* big, const float* small, float* dw_ref, int B, int H, int W, int Cbig, int Csmall,
+                                void* ws, size_t ws_bytes, vp_stream stream) {
+  VP_REQUIRE(big && small && dw_ref && ws && B > 0 && H > 0 && W > 0, "vp_conv5_smallout_wgrad_f32: bad arguments");
+  VP_REQUIRE(((uintptr_t)big & 15) == 0, "vp_conv5_smallout_wgrad_f32: the activation must be 16-byte aligned");
+  const ConvGeom g = make_geom(B, H, W, Csmall, Cbig, 1);
+  VP_REQUIRE(tapm_wgrad_applicable(g), "vp_conv5_smallout_wgrad_f32: needs 64 input channels, 1 or 3 outputs, width a multiple of 64, height of 8");
+  if (ws_bytes < tapm_wgrad_ws_floats(g) * sizeof(float)) return fail(VP_ERR_WORKSPACE, "vp_conv5_smallout_wgrad_f32: workspace too small");
+  return tapm_wgrad_f32_launch(big, small, dw_ref, g, (float*)ws, (hipStream_t)stream);
 }
 
 int vp_conv5_smallin_dgrad_bf16x3(const float* small, const float* w_ref, float* big_out, int B, int H, int W, int Csmall, int Cbig,

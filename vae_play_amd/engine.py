@@ -541,10 +541,10 @@ class FusedVAEStep:
         ws_cs = self._ws("g.colsum.ws", lib.vp_colsum_workspace_bytes(B * S * S, C))
         bwd.add("vp_colsum_f32", P(dlogit), P(grad_of(fin.bias)), B * S * S, C, P(ws_cs), ws_cs.numel() * 4, side=side_slot())
         ws_wg = self._ws("g.wgrad.ws", self._max_wgrad_ws(enc_rec, dec_rec, Cf))
-        n_tapm = lib.vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(B, S, S, Cf, C) if x3 else 0
-        if n_tapm:      # split-bf16 on the matrix cores, taps folded into the MFMA rows (csrc/edge.hip); its own slab workspace
+        n_tapm = lib.vp_conv5_smallout_wgrad_bf16x3_workspace_bytes(B, S, S, Cf, C)      # (the exact-f32 form takes the same slabs)
+        if n_tapm:      # on the matrix cores, taps folded into the MFMA rows (csrc/edge.hip); its own slab workspace
             ws_fw = self._ws("g.finwgrad.ws", n_tapm)
-            bwd.add("vp_conv5_smallout_wgrad_bf16x3", P(dec_in[-1]), P(dlogit), P(grad_of(fin.weight)), B, S, S, Cf, C, P(ws_fw),
+            bwd.add("vp_conv5_smallout_wgrad_bf16x3" if x3 else "vp_conv5_smallout_wgrad_f32", P(dec_in[-1]), P(dlogit), P(grad_of(fin.weight)), B, S, S, Cf, C, P(ws_fw),
                     ws_fw.numel() * 4, flops=50.0 * B * S * S * Cf * C, tag="fin.wgrad", side=side_slot())
         else:
             bwd.add("vp_conv5_wgrad_f32", P(dec_in[-1]), P(dlogit), P(grad_of(fin.weight)), B, S, S, Cf, C, 1, P(ws_wg), ws_wg.numel() * 4,
