@@ -42,7 +42,8 @@ CONV_CALLS = {"vp_conv5_gather_f32", "vp_conv5_scatter_f32", "vp_conv5_wgrad_f32
               "vp_conv5_smallin_dgrad_bf16x3", "vp_conv5_smallout_bf16x3", "vp_conv5_smallout_wgrad_bf16x3", "vp_conv5_gather_f16", "vp_conv5_scatter_f16", "vp_conv5_wgrad_f16x2", "vp_conv5_gather_stats_f16",
               "vp_conv5_scatter_stats_f16", "vp_conv_gather_f16", "vp_conv_wgrad_f16x2",
               "vp_conv5_wgrad_bf16x3_cus", "vp_conv5_wgrad_f16x2_cus", "vp_conv5_wgrad_f32_cus",
-              "vp_conv5_gather_stats_f32", "vp_conv5_scatter_stats_f32", "vp_conv5_smallin_dgrad_f32", "vp_conv5_smallout_wgrad_f32"}
+              "vp_conv5_gather_stats_f32", "vp_conv5_scatter_stats_f32", "vp_conv5_smallin_dgrad_f32", "vp_conv5_smallout_wgrad_f32",
+              "vp_conv_gather_f32", "vp_conv_wgrad_f32"}
 
 
 def mfma_products(name, tag):

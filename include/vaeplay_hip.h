@@ -144,6 +144,10 @@ int vp_im2col5s2_cols(int C);
 int vp_im2col5s2_split_f32(const float* x, void* out_split, int B, int C, int Hb, int Wb, int nchw, vp_stream stream);
 int vp_pack_w_im2col5_split(const float* w_ref, void* out_split, int Cout, int C, vp_stream stream);
 int vp_unpack_dw_im2col5_f32(const float* dw_cols, float* dw_ref, int Cout, int C, vp_stream stream);
+/* The same im2col and weight re-ordering as plain fp32 ([B*Hs*Ws][KC] and [Cout][KC]) for the exact-f32 plan: the first conv and its
+ * weight gradient then run as 1x1 layers through vp_conv_gather_f32 / vp_conv_wgrad_f32 (ks = 1) on the fp32 matrix cores. */
+int vp_im2col5s2_f32(const float* x, float* out, int B, int C, int Hb, int Wb, int nchw, vp_stream stream);
+int vp_pack_w_im2col5_f32(const float* w_ref, float* out, int Cout, int C, vp_stream stream);
 /* Convolution + BatchNorm batch statistics in one call (replaces nn.Conv2d / nn.ConvTranspose2d followed by the statistics
  * pass of nn.BatchNorm2d(momentum=0.9), models/networks.py:14-16,27-28 and :38-40,43-44): the convolution's epilogue emits
  * per-workgroup {pivot, sum(x - pivot), sum((x - pivot)^2)} per output channel from its accumulators and one finaliser

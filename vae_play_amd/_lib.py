@@ -58,6 +58,8 @@ SIGNATURES = {
     "vp_im2col5s2_split_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vp_pack_w_im2col5_split": (c_int, [P, P, c_int, c_int, P]),
     "vp_unpack_dw_im2col5_f32": (c_int, [P, P, c_int, c_int, P]),
+    "vp_im2col5s2_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vp_pack_w_im2col5_f32": (c_int, [P, P, c_int, c_int, P]),
     "vp_conv5_stats_workspace_bytes": (c_size_t, [c_int] * 7),
     "vp_conv5_gather_stats_bf16x3": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),
     "vp_conv5_gather_stats_f32": (c_int, [P, P, P] + [c_int] * 6 + [c_float, c_float, P, P, P, P, P, c_size_t, P]),

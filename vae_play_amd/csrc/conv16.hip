@@ -177,6 +177,36 @@ __global__ void __launch_bounds__(256) im2col5s2_split_kernel(const float* __res
   }
 }
 
+// the same im2col as fp32 [pixel][KC] (exact-f32 plan: both 1x1 layers then run on the fp32-MFMA kernels)
+template <int C>
+__global__ void __launch_bounds__(256) im2col5s2_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int Hb, int Wb,
+                                                            int Hs, int Ws, int nchw) {
+  constexpr int GW = C == 3 ? 16 : 8, KC = ((5 * GW + 31) / 32) * 32, G = KC / 4;
+  const int row = blockIdx.x, b = row / Hs, hs = row - b * Hs;
+  for (int i = threadIdx.x; i < Ws * G; i += blockDim.x) {
+    const int ws = i / G, c0 = (i - ws * G) * 4;
+    vp_f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = c0 + j, r = col / GW, rem = col - r * GW;
+      const int q = rem / C, cin = rem - q * C;
+      const int h = 2 * hs - 2 + r, w_ = 2 * ws - 2 + q;
+      const bool ok = r < 5 && q < 5 && h >= 0 && h < Hb && w_ >= 0 && w_ < Wb;
+      v[j] = ok ? (nchw ? x[(((size_t)b * C + cin) * Hb + h) * Wb + w_] : x[(((size_t)b * Hb + h) * Wb + w_) * C + cin]) : 0.f;
+    }
+    *reinterpret_cast<vp_f32x4*>(out + ((size_t)row * Ws + ws) * KC + c0) = v;
+  }
+}
+
+__global__ void pack_w_im2col5_f32_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int C, int GW, int KC) {
+  const size_t n = (size_t)Cout * KC;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i / KC), col = (int)(i - (size_t)co * KC);
+    const int r = col / GW, rem = col - r * GW, q = rem / C, cin = rem - q * C;
+    out[i] = (r < 5 && q < 5) ? w[(((size_t)co * C + cin) * 5 + r) * 5 + q] : 0.f;
+  }
+}
+
 // w_ref [Cout][C][5][5] -> split planes [Cout][KC] in the im2col column order (zero columns where no tap lives)
 __global__ void pack_w_im2col5_split_kernel(const float* __restrict__ w, u16_t* __restrict__ out, int Cout, int C, int GW, int KC,
                                             int fmt) {
@@ -442,6 +472,24 @@ int vp_im2col5s2_split_fmt_f32(const float* x, void* out_split, int B, int C, in
 
 int vp_im2col5s2_split_f32(const float* x, void* out_split, int B, int C, int Hb, int Wb, int nchw, vp_stream stream) {
   return vp_im2col5s2_split_fmt_f32(x, out_split, B, C, Hb, Wb, nchw, SPLIT_BF16, stream);
+}
+
+int vp_im2col5s2_f32(const float* x, float* out, int B, int C, int Hb, int Wb, int nchw, vp_stream stream) {
+  VP_REQUIRE(x && out && B > 0 && Hb > 0 && Wb > 0 && Hb % 2 == 0 && Wb % 2 == 0, "vp_im2col5s2_f32: bad arguments");
+  VP_REQUIRE(C == 1 || C == 3, "vp_im2col5s2_f32: 1 or 3 image channels");
+  VP_REQUIRE(((uintptr_t)out & 15) == 0, "vp_im2col5s2_f32: the output must be 16-byte aligned");
+  const dim3 grid((unsigned)(B * (Hb / 2)));
+  if (C == 3) hipLaunchKernelGGL((im2col5s2_f32_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, x, out, B, Hb, Wb, Hb / 2, Wb / 2, nchw);
+  else hipLaunchKernelGGL((im2col5s2_f32_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, out, B, Hb, Wb, Hb / 2, Wb / 2, nchw);
+  return check_launch("vp_im2col5s2_f32");
+}
+
+int vp_pack_w_im2col5_f32(const float* w_ref, float* out, int Cout, int C, vp_stream stream) {
+  VP_REQUIRE(w_ref && out && Cout > 0 && (C == 1 || C == 3), "vp_pack_w_im2col5_f32: bad arguments");
+  const int KC = im2col5_kc(C), GW = im2col5_gw(C);
+  hipLaunchKernelGGL(pack_w_im2col5_f32_kernel, dim3(grid_for((size_t)Cout * KC, 256)), dim3(256), 0, (hipStream_t)stream, w_ref, out, Cout, C,
+                     GW, KC);
+  return check_launch("vp_pack_w_im2col5_f32");
 }
 
 int vp_pack_w_im2col5_split_fmt(const float* w_ref, void* out_split, int Cout, int C, int fmt, vp_stream stream) {

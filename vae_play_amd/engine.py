@@ -384,6 +384,9 @@ class FusedVAEStep:
         sp = [S // (2 ** i) for i in range(L + 1)]
         enc16 = [use16(enc_ch[i], enc_ch[i + 1]) for i in range(L)]
         enc0_cols = x3 and C in (1, 3) and enc_ch[1] % 8 == 0
+        # exact f32: the same im2col as plain fp32, both 1x1 layers on the fp32-MFMA kernels (the 3-channel implicit GEMM and the VALU
+        # weight gradient took 48 + 67 us at the benchmark shard, the two 1x1 layers 36 + 40 + 20 us of im2col / re-order: 7.63 -> 7.60 ms)
+        enc0_cols32 = (not x3) and C in (1, 3) and enc_ch[1] % 16 == 0
         enc_in = [x_nhwc]        # fp32 inputs (None when only the split copy exists)
         enc_in_s = [None]        # split inputs
         enc_rec = []
@@ -411,6 +414,15 @@ class FusedVAEStep:
                     fwd.add("vp_pack_w_im2col5_split", P(blk.conv.weight), P(w0s), Cout, Cin)
                     fwd.add("vp_conv_gather_bf16x3", P(xcol), P(w0s), None, P(c), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, _ACT_NONE,
                             flops=fl, tag="enc0.fwd")
+                p1 = None
+            elif i == 0 and enc0_cols32:
+                KC = lib.vp_im2col5s2_cols(Cin)
+                xcol = self._buf("enc0.xcol32", B * Hs * Hs * KC)
+                w0 = self._buf("enc0.w0", Cout * KC)
+                self._enc0 = (xcol, KC)
+                fwd.add("vp_im2col5s2_f32", P(self.x_nchw), P(xcol), B, Cin, S, S, 1)
+                fwd.add("vp_pack_w_im2col5_f32", P(blk.conv.weight), P(w0), Cout, Cin)
+                fwd.add("vp_conv_gather_f32", P(xcol), P(w0), None, P(c), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, _ACT_NONE, flops=fl, tag="enc0.fwd")
                 p1 = None
             elif enc16[i]:
                 p0 = self._sbuf(f"enc{i}.p0s", Cout * 25 * Cin)
@@ -683,6 +695,14 @@ class FusedVAEStep:
                 if i == max(L - 2, 1):
                     # the gradients of encoder.conv[i:] (16.4 of the 17 MB of conv parameters at config 3) are issued: third bucket
                     self._bwd_b_enc_tail, self._enc_tail_first = len(bwd.calls), i
+            elif i == 0 and enc0_cols32:
+                xcol, KC = self._enc0
+                bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)            # other = d c_0
+                dwc = self._buf("enc0.dwc", Cout * KC)
+                ws0 = self._ws("enc0.wgws", lib.vp_conv_wgrad_workspace_bytes(B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1))
+                bwd.add("vp_conv_wgrad_f32", P(xcol), P(other), P(dwc), B, Hs, Hs, Hs, Hs, KC, Cout, 1, 1, P(ws0), ws0.numel() * 4,
+                        flops=fl, tag="enc0.wgrad")
+                bwd.add("vp_unpack_dw_im2col5_f32", P(dwc), P(grad_of(blk.conv.weight)), Cout, Cin)
             else:
                 bn_block_bwd2(c, cur, other, R, Cout, blk.bn, mean, rstd, ws)            # other = d c_i
                 # side stream only for the last layer of the walk (i == 0): nothing rewrites `other` after it
