@@ -1,5 +1,6 @@
 // Split-bf16 ("bf16x3") convolution families: C ABI + the producers of split planes.
 #define VP_PCFG_LIBRARY 1
+#define VP_IGEMM16_M16_ON 1
 #include "conv16_impl.h"
 
 namespace vp {

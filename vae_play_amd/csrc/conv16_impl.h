@@ -21,6 +21,18 @@ static int xcd_map_for(long M, long N, int gz, int ctile = 0) {
 }
 
 static bool halo_enabled() { return true; }
+// Where the register-staged gather / scatter kernels run their v_mfma_f32_16x16x32_bf16 form (igemm16.h M16; VP_IGEMM16_M16=0: nowhere).
+// Measured per layer in the step at 32 images (profiles/r03_notes.md section 11): the 128x128 tile gains 4 - 5 % in both families
+// (dec1.fwd 180 -> 171 us, dec2.fwd 175 -> 166, dec3.dgrad 174 -> 167), the scatter family's 128x64 tile 2 % on its largest launch
+// (dec3.fwd 239 -> 234); the gather family's 128x64 tile loses 8 % (dec1.dgrad) and the 64x64 tile up to 12 % (enc2.fwd): not taken.
+static bool igemm16_m16_rule(bool scatter, long M, long N, int gz, int ctile) {
+  const char* e = VP_GETENV("VP_IGEMM16_M16");
+  if (e && atoi(e) == 0) return false;
+  if (ctile <= 0 || ctile % 64 != 0) return false;
+  const Tile16 t = choose_tile16(M, N, gz, false, ctile);
+  if (t.bm != 128) return false;
+  return t.bn == 128 || (scatter && t.bn == 64 && M >= 65536);
+}
 
 // layers with fewer output tiles than this split K in two
 static long conv_split_tiles() { return 384; }
@@ -104,7 +116,7 @@ static int gather16_t(const void* big_split, const void* w_p0_split, const float
     }
   }
   p.xcd_map = xcd_map_for(p.M, p.N, p.nsplit, Cbig);
-  launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig);
+  launch_igemm16(p, p.M, p.N, p.nsplit, (hipStream_t)stream, Cbig, std::is_same<PF, ProbF16>::value && igemm16_m16_rule(false, p.M, p.N, p.nsplit, Cbig));
   return check_launch("vp_conv_gather_bf16x3");
 }
 
@@ -140,7 +152,7 @@ static int scatter16_t(const void* small_split, const void* w_p1_split, float* b
     const long wgs = ((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn) * stride * stride * p.nsplit;
     p.pair_phases = (stride == 2 && p.nsplit == 1 && wgs <= 512) ? 1 : 0;
   }
-  launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall);
+  launch_igemm16(p, p.M, p.N, stride * stride * p.nsplit, (hipStream_t)stream, Csmall, std::is_same<PT, ProbT16>::value && igemm16_m16_rule(true, p.M, p.N, stride * stride * p.nsplit, Csmall));
   return check_launch("vp_conv_scatter_bf16x3");
 }
 

@@ -71,6 +71,7 @@ struct ProbF16T {
   // host doubles the gathered channel count: [pix][C] fp32 = [pix][2C] u16), a 16-B chunk = 4 floats, a 64-deep K-tile = 32 floats;
   // every fragment pair is contracted by four v_mfma_f32_32x32x2_f32.  Gather / scatter families only.
   static constexpr bool F32 = MODE_ == 3;
+  static constexpr bool IS_K5 = K5;
   float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
@@ -183,6 +184,7 @@ struct ProbT16T {
   // host doubles the gathered channel count: [pix][C] fp32 = [pix][2C] u16), a 16-B chunk = 4 floats, a 64-deep K-tile = 32 floats;
   // every fragment pair is contracted by four v_mfma_f32_32x32x2_f32.  Gather / scatter families only.
   static constexpr bool F32 = MODE_ == 3;
+  static constexpr bool IS_K5 = K5;
   float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
@@ -318,6 +320,7 @@ struct ProbW16T {
   // host doubles the gathered channel count: [pix][C] fp32 = [pix][2C] u16), a 16-B chunk = 4 floats, a 64-deep K-tile = 32 floats;
   // every fragment pair is contracted by four v_mfma_f32_32x32x2_f32.  Gather / scatter families only.
   static constexpr bool F32 = MODE_ == 3;
+  static constexpr bool IS_K5 = K5;
   float alpha = 1.f;                  // F16: the accumulators are multiplied by alpha before the epilogue (undoes a producer's scale)
   // K5: the 5x5 / padding-2 / Hb = stride*Hs case of the VAE layers with its constants folded in (the generic form costs
   // the hot path ~1 %); !K5: kernel size, padding and the big image size come from the geometry (models/blocks.py)
@@ -501,8 +504,58 @@ __device__ __forceinline__ void epilogue_stats32(float* __restrict__ stat, int g
   }
 }
 
-template <class P, int BM, int BN, int WM, int WN, int BKT, bool FAST>
-__global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
+// The same statistics from the accumulators of the 16x16x32 form (lane = column lane % 16 of a 16-column block, rows 4 * (lane / 16) + r
+// in the 4 registers): the four lane groups are combined by shuffles, the wave rows through LDS, in a fixed order.
+typedef float f32x4_t16 __attribute__((ext_vector_type(4)));
+template <int BM, int BN, int WM, int WN, int TM16, int TN16>
+__device__ __forceinline__ void epilogue_stats16(float* __restrict__ stat, int groups, int group, int M, int N, const f32x4_t16 (&acc)[TM16][TN16],
+                                                 unsigned char* lds, int m0, int n0, int wm, int wn, int lane, int tid) {
+  float* pv = reinterpret_cast<float*>(lds);      // [BN] pivots
+  float* red = pv + BN;                            // [WM][BN][2]
+  const int lc = lane & 15, lg = lane >> 4;
+  if (wm == 0 && lg == 0) {
+#pragma unroll
+    for (int j = 0; j < TN16; ++j) pv[wn * (BN / WN) + 16 * j + lc] = acc[0][j][0];   // row m0 (always < M)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN16; ++j) {
+    const int col = wn * (BN / WN) + 16 * j + lc;
+    const float pvt = pv[col];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * (BM / WM) + 16 * i + 4 * lg + r;
+        const float d = m < M ? acc[i][j][r] - pvt : 0.f;
+        s += d;
+        q += d * d;
+      }
+    s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+    s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+    if (lg == 0) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < N) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+    const size_t n = (size_t)(n0 + tid);
+    stat[(0 * (size_t)N + n) * groups + group] = pv[tid];
+    stat[(1 * (size_t)N + n) * groups + group] = s;
+    stat[(2 * (size_t)N + n) * groups + group] = q;
+  }
+}
+
+// M16: contract with v_mfma_f32_16x16x32_bf16 (one MFMA = a 32-deep k-step of a 16 x 16 block; same FLOPs per cycle as the 32x32x16
+// form, lower power per product: tools/kbench measured +5 - 8 % in-kernel clock).  Gather / scatter families on bf16 pairs only
+// (k-contiguous operands: a fragment is the same 16-B read at row lane % 16, k chunk lane / 16 -- the 144-B row pitch covers all 64
+// banks per 16-lane group as it does for the 32x32 form).  Results equal the 32x32x16 form's to rounding (another summation order).
+// (the 128x128 tile of this form needs ~200 registers if left alone -- one workgroup per CU, 40 % slower: its launch bounds ask for two)
+template <class P, int BM, int BN, int WM, int WN, int BKT, bool FAST, bool M16 = false>
+__global__ void __launch_bounds__(256, (M16 && BM * BN >= 128 * 128) ? 2 : 1) igemm16_kernel(const P p) {
+  static_assert(!M16 || (!P::A_KM && !P::B_KM && P::MODE == 0 && BKT % 32 == 0), "16x16x32 form: k-contiguous bf16-pair operands");
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(BKT == 32 || BKT == 64, "K-tile depth");
   constexpr int SH = BKT == 64 ? 6 : 5;       // FAST gather/scatter kernels decompose k0 in BKT-deep channel chunks
@@ -714,6 +767,80 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
     }
   };
 
+  const int klen = z.k_end - z.k_begin;
+  const int nk = klen > 0 ? (klen + BKT - 1) / BKT : 0;
+
+  if constexpr (M16) {
+    constexpr int TM16 = BM / WM / 16, TN16 = BN / WN / 16;
+    f32x4_t16 acc16[TM16][TN16];
+#pragma unroll
+    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+      for (int j = 0; j < TN16; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+    const int lc = lane & 15, lg = lane >> 4;
+    const unsigned char* const a0 = As + (wm * (BM / WM) + lc) * MKS + lg * 16;
+    const unsigned char* const b0 = Bs + (wn * (BN / WN) + lc) * MKS + lg * 16;
+    if (nk > 0) {
+      stage_load(z.k_begin);
+      stage_write();
+      __syncthreads();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (more) stage_load(z.k_begin + (kt + 1) * BKT);
+#pragma unroll
+      for (int s = 0; s < BKT / 32; ++s) {
+        // (the wave's row blocks in halves: 16 + 32 fragment registers live instead of 64 -- two workgroups per CU on the 128x128 tile)
+        constexpr int TMH = TM16 >= 2 ? TM16 / 2 : TM16;
+        bf16x8_t bh[TN16], bl[TN16];
+#pragma unroll
+        for (int j = 0; j < TN16; ++j) {
+          bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(b0 + 16 * j * MKS + s * 64));
+          bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(b0 + B_PLANE + 16 * j * MKS + s * 64));
+        }
+#pragma unroll
+        for (int h = 0; h < TM16 / TMH; ++h) {
+          bf16x8_t ah[TMH], al[TMH];
+#pragma unroll
+          for (int i = 0; i < TMH; ++i) {
+            ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(a0 + 16 * (h * TMH + i) * MKS + s * 64));
+            al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(a0 + A_PLANE + 16 * (h * TMH + i) * MKS + s * 64));
+          }
+#pragma unroll
+          for (int i = 0; i < TMH; ++i)
+#pragma unroll
+            for (int j = 0; j < TN16; ++j) {
+              f32x4_t16 c = acc16[h * TMH + i][j];
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], c, 0, 0, 0);
+              acc16[h * TMH + i][j] = c;
+            }
+        }
+      }
+      __syncthreads();
+      if (more) {
+        stage_write();
+        __syncthreads();
+      }
+    }
+    if constexpr (P::HAS_STAT) {
+      if (p.stat)
+        epilogue_stats16<BM, BN, WM, WN, TM16, TN16>(p.stat, (int)(gridDim.x * gridDim.z), (int)(tz * gridDim.x) + tx, p.M, p.N, acc16, lds, m0,
+                                                     n0, wm, wn, lane, tid);
+    }
+#pragma unroll
+    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+      for (int j = 0; j < TN16; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          p.store(m0 + wm * (BM / WM) + 16 * i + 4 * lg + r, n0 + wn * (BN / WN) + 16 * j + lc, acc16[i][j][r], z);
+    return;
+  }
+
   f32x16_t acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -722,8 +849,6 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int klen = z.k_end - z.k_begin;
-  const int nk = klen > 0 ? (klen + BKT - 1) / BKT : 0;
   const int arow0 = wm * (BM / WM) + li;
   const int brow0 = wn * (BN / WN) + li;
 
@@ -783,6 +908,9 @@ __global__ void __launch_bounds__(256) igemm16_kernel(const P p) {
       }
 }
 
+#ifndef VP_IGEMM16_M16_ON
+#define VP_IGEMM16_M16_ON 0      // translation units that dispatch the 16x16x32 form of igemm16_kernel define it to 1 (conv16.hip)
+#endif
 struct Tile16 { int bm, bn; };   // wave grid: 2 x 2, or 4 x 1 for the 32-column tiles
 
 inline Tile16 choose_tile16(long M, long N, int gz, bool /*pixel_major*/ = false, int ctile = 0) {
@@ -810,10 +938,17 @@ inline int igemm16_bk(bool km, bool x2 = false) {
 }
 
 template <class P, int BKT, bool FAST>
-inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0) {
+inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0, bool m16 = false) {
   Tile16 t = choose_tile16(M, N, gz, P::A_KM, ctile);
   dim3 block(256);
   auto grid = [&](int bm, int bn) { return dim3((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)gz); };
+  if constexpr (VP_IGEMM16_M16_ON && !P::A_KM && !P::B_KM && P::MODE == 0 && P::IS_K5 && BKT == 64 && FAST) {
+    if (m16 && t.bm == 128 && (t.bn == 128 || t.bn == 64)) {      // the 16x16x32 form of the same tiles (the host decides where: igemm16_m16_rule)
+      if (t.bn == 128) hipLaunchKernelGGL((igemm16_kernel<P, 128, 128, 2, 2, BKT, FAST, true>), grid(128, 128), block, 0, stream, p);
+      else hipLaunchKernelGGL((igemm16_kernel<P, 128, 64, 2, 2, BKT, FAST, true>), grid(128, 64), block, 0, stream, p);
+      return;
+    }
+  }
   if (t.bm == 128 && t.bn == 128) {
     hipLaunchKernelGGL((igemm16_kernel<P, 128, 128, 2, 2, BKT, FAST>), grid(128, 128), block, 0, stream, p);
   } else if (t.bm == 128 && t.bn == 64) {
@@ -832,7 +967,7 @@ inline void launch_igemm16_bk(const P& p, long M, long N, int gz, hipStream_t st
 // ctile = the channel count that k is decomposed by (0 for the pixel-major wgrad family): FAST kernels
 // are used when it is a multiple of the K-tile depth.
 template <class P>
-inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0) {
+inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t stream, int ctile = 0, bool m16 = false) {
   const int bk = igemm16_bk(P::A_KM, P::X2);
   if constexpr (P::A_KM) {
     // pixel-major (wgrad) family: FAST when the chosen tile lies fully inside M x N (no channel tails)
@@ -853,7 +988,7 @@ inline void launch_igemm16(const P& p, long M, long N, int gz, hipStream_t strea
   } else {
     const Tile16 t0 = choose_tile16(M, N, gz, false, ctile);
     const bool narrow = t0.bn == 32;   // tiles that exist with 32-deep K-tiles only
-    if (ctile > 0 && ctile % 64 == 0 && bk == 64 && !narrow) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream, ctile);
+    if (ctile > 0 && ctile % 64 == 0 && bk == 64 && !narrow) launch_igemm16_bk<P, 64, true>(p, M, N, gz, stream, ctile, m16);
     else if (ctile > 0 && ctile % 32 == 0) launch_igemm16_bk<P, 32, true>(p, M, N, gz, stream, ctile);   // 32-channel chunks
     else if (bk == 32 || narrow) launch_igemm16_bk<P, 32, false>(p, M, N, gz, stream, ctile);
     else launch_igemm16_bk<P, 64, false>(p, M, N, gz, stream, ctile);
