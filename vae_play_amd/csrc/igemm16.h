@@ -27,6 +27,9 @@
 
 namespace vp {
 
+#ifndef VP_IGEMM16_SWZ_ON
+#define VP_IGEMM16_SWZ_ON 1      // swizzled, unpadded LDS rows for the 128x64 tile (see igemm16_kernel); 0: the padded rows everywhere
+#endif
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -439,9 +442,14 @@ template <class P, int NR> struct Rows16B<P, NR, false> { typename P::BRow r[NR]
 template <class P, int NR> struct Rows16B<P, NR, true> {};
 
 // fragment fetch: 8 bf16 (k = 8*lh .. 8*lh+7 of MFMA step s) of tile row/column `row`
-template <int BR, bool KM, int BKT>
+// SWZ (k-contiguous rows of 64 elements only): 128-B rows without padding, the 16-B chunk index XOR-ed with (row >> 1) & 7 -- sixteen
+// consecutive rows then cover all 64 banks with one chunk each (8 * (row & 1) + chunk ^ swizzle takes 16 distinct values)
+template <int BR, bool KM, int BKT, bool SWZ = false>
 __device__ __forceinline__ bf16x8_t frag16(const unsigned char* plane, int row, int s, int li, int lh, int lane) {
-  if constexpr (!KM) {
+  if constexpr (!KM && SWZ) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(plane + row * 128 + (((s * 2 + lh) ^ ((row >> 1) & 7)) << 4));
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else if constexpr (!KM) {
     const u32x4_t v = *reinterpret_cast<const u32x4_t*>(plane + row * MkStride<BKT>::bytes + s * 32 + lh * 16);
     return __builtin_bit_cast(bf16x8_t, v);
   } else {
@@ -563,9 +571,13 @@ __global__ void __launch_bounds__(256, (M16 && BM * BN >= 128 * 128) ? 2 : 1) ig
   static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
   constexpr int KC = BKT / 8;                 // 16-B chunks per row and plane
   constexpr int NA_KM = BM * KC / 128, NB_KM = BN * KC / 128;   // 16-B chunks per thread per K-tile (both planes)
-  constexpr int A_PLANE = Lds16<BM, P::A_KM, BKT>::plane_bytes;
-  constexpr int B_PLANE = Lds16<BN, P::B_KM, BKT>::plane_bytes;
-  constexpr int MKS = MkStride<BKT>::bytes;
+  // SWZ: the 128x64 tile on 64-deep k-contiguous planes stores unpadded, swizzled rows (frag16): 49 KB instead of 55 KB of LDS = THREE
+  // workgroups per CU instead of two
+  constexpr bool SWZ = VP_IGEMM16_SWZ_ON && !P::A_KM && !P::B_KM && !P::F32 && BM == 128 && BN == 64 && BKT == 64;
+  constexpr int A_PLANE = SWZ ? BM * 128 + 64 : Lds16<BM, P::A_KM, BKT>::plane_bytes;
+  constexpr int B_PLANE = SWZ ? BN * 128 + 64 : Lds16<BN, P::B_KM, BKT>::plane_bytes;
+  constexpr int MKS = SWZ ? 128 : MkStride<BKT>::bytes;
+  auto swz = [](int row, int chunk) { return SWZ ? (chunk ^ ((row >> 1) & 7)) : chunk; };
   // MK staging map: 4 threads per row; a thread stages, for BM/64 (BN/64) rows, CPT chunks of the row:
   // both planes x the k-chunks {l4*CPH .. l4*CPH+CPH-1}.  One bounds test / address per row serves all
   // its chunks (FAST path), a 4-lane group reads 64 contiguous bytes per plane, and an 8-lane
@@ -732,7 +744,7 @@ __global__ void __launch_bounds__(256, (M16 && BM * BN >= 128 * 128) ? 2 : 1) ig
       for (int i = 0; i < NRA; ++i)
 #pragma unroll
         for (int j = 0; j < CPH; ++j) {
-          unsigned char* dst = As + (srow + RPP * i) * MKS + (l4 * CPH + j) * 16;
+          unsigned char* dst = As + (srow + RPP * i) * MKS + swz(srow + RPP * i, l4 * CPH + j) * 16;
           *reinterpret_cast<u32x4_t*>(dst) = sa[i * CPT + j];
           if constexpr (A_LO) *reinterpret_cast<u32x4_t*>(dst + A_PLANE) = sa[i * CPT + CPH + j];
         }
@@ -751,7 +763,7 @@ __global__ void __launch_bounds__(256, (M16 && BM * BN >= 128 * 128) ? 2 : 1) ig
       for (int i = 0; i < NRB; ++i)
 #pragma unroll
         for (int j = 0; j < CPH; ++j) {
-          unsigned char* dst = Bs + (srow + RPP * i) * MKS + (l4 * CPH + j) * 16;
+          unsigned char* dst = Bs + (srow + RPP * i) * MKS + swz(srow + RPP * i, l4 * CPH + j) * 16;
           *reinterpret_cast<u32x4_t*>(dst) = sb[i * CPT + j];
           if constexpr (B_LO) *reinterpret_cast<u32x4_t*>(dst + B_PLANE) = sb[i * CPT + CPH + j];
         }
@@ -780,8 +792,10 @@ __global__ void __launch_bounds__(256, (M16 && BM * BN >= 128 * 128) ? 2 : 1) ig
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
     const int lc = lane & 15, lg = lane >> 4;
-    const unsigned char* const a0 = As + (wm * (BM / WM) + lc) * MKS + lg * 16;
-    const unsigned char* const b0 = Bs + (wn * (BN / WN) + lc) * MKS + lg * 16;
+    // (row blocks are 16 rows apart: (row >> 1) & 7 -- the swizzle -- is the same for every block of a lane)
+    const int arow = wm * (BM / WM) + lc, brow = wn * (BN / WN) + lc;
+    const unsigned char* const a0 = As + arow * MKS;
+    const unsigned char* const b0 = Bs + brow * MKS;
     if (nk > 0) {
       stage_load(z.k_begin);
       stage_write();
@@ -797,16 +811,16 @@ __global__ void __launch_bounds__(256, (M16 && BM * BN >= 128 * 128) ? 2 : 1) ig
         bf16x8_t bh[TN16], bl[TN16];
 #pragma unroll
         for (int j = 0; j < TN16; ++j) {
-          bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(b0 + 16 * j * MKS + s * 64));
-          bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(b0 + B_PLANE + 16 * j * MKS + s * 64));
+          bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(b0 + 16 * j * MKS + swz(brow, 4 * s + lg) * 16));
+          bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(b0 + B_PLANE + 16 * j * MKS + swz(brow, 4 * s + lg) * 16));
         }
 #pragma unroll
         for (int h = 0; h < TM16 / TMH; ++h) {
           bf16x8_t ah[TMH], al[TMH];
 #pragma unroll
           for (int i = 0; i < TMH; ++i) {
-            ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(a0 + 16 * (h * TMH + i) * MKS + s * 64));
-            al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(a0 + A_PLANE + 16 * (h * TMH + i) * MKS + s * 64));
+            ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(a0 + 16 * (h * TMH + i) * MKS + swz(arow, 4 * s + lg) * 16));
+            al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(a0 + A_PLANE + 16 * (h * TMH + i) * MKS + swz(arow, 4 * s + lg) * 16));
           }
 #pragma unroll
           for (int i = 0; i < TMH; ++i)
@@ -865,15 +879,15 @@ __global__ void __launch_bounds__(256, (M16 && BM * BN >= 128 * 128) ? 2 : 1) ig
       bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = frag16<BM, P::A_KM, BKT>(As, arow0 + 32 * i, s, li, lh, lane);
-        if constexpr (A_LO) al[i] = frag16<BM, P::A_KM, BKT>(As + A_PLANE, arow0 + 32 * i, s, li, lh, lane);
+        ah[i] = frag16<BM, P::A_KM, BKT, SWZ>(As, arow0 + 32 * i, s, li, lh, lane);
+        if constexpr (A_LO) al[i] = frag16<BM, P::A_KM, BKT, SWZ>(As + A_PLANE, arow0 + 32 * i, s, li, lh, lane);
         else al[i] = ah[i];
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = frag16<BN, P::B_KM, BKT>(Bs, brow0 + 32 * j, s, li, lh, lane);
+        bh[j] = frag16<BN, P::B_KM, BKT, SWZ>(Bs, brow0 + 32 * j, s, li, lh, lane);
         if constexpr (!B_LO) bl[j] = bh[j];      // not read by the two-product / fp32 forms
-        else bl[j] = frag16<BN, P::B_KM, BKT>(Bs + B_PLANE, brow0 + 32 * j, s, li, lh, lane);
+        else bl[j] = frag16<BN, P::B_KM, BKT, SWZ>(Bs + B_PLANE, brow0 + 32 * j, s, li, lh, lane);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
