@@ -25,3 +25,19 @@ def test_pipelined_kernel_equals_register_staged_kernel(args):
         assert not bad, f"kernel mismatch: {what}\n" + out.stdout[-3000:]
         if what.startswith("bit="):
             assert what == "bit=0", what
+
+
+SBENCH = os.path.join(ROOT, "tools", "kbench", "sbench")
+
+
+def test_two_phase_halo_patch_prototype_equals_library_kernel():
+    """tools/kbench/scatter5.h (prototype, not in the library: transposed-conv forward with two phases per workgroup from one halo patch)
+    against the library's vp_conv5_scatter_bf16x3 on every layer shape it takes: equal to rounding (another summation order over k)."""
+    if not os.path.exists(SBENCH):
+        pytest.fail("tools/kbench/sbench is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    out = subprocess.run([SBENCH, "B=4", "img=128", "reps=1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cells = re.findall(r"new vs old: max\|d\|/rms = ([\d.e+-]+), (\d+) NaN( !!!)?", out.stdout)
+    assert len(cells) >= 5, out.stdout[-2000:]
+    for rel, nan, bad in cells:
+        assert not bad and int(nan) == 0 and float(rel) <= 3e-5, out.stdout[-3000:]

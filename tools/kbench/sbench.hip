@@ -154,7 +154,7 @@ int main(int argc, char** argv) {
         ss += (double)ho[i] * ho[i];
       }
       const double rms = sqrt(ss / out_n + 1e-300);
-      printf(" | new vs old: max|d|/rms = %.2e, %zu NaN%s", mx / rms, bad, (mx / rms > 1e-5 || bad) ? " !!!" : "");
+      printf(" | new vs old: max|d|/rms = %.2e, %zu NaN%s", mx / rms, bad, (mx / rms > 3e-5 || bad) ? " !!!" : "");
     } else {
       printf(" new: shape not taken");
     }
